@@ -1,0 +1,122 @@
+/* libsdhip -- C ABI of the MI355X-native (gfx950) Stable Diffusion sampling hot path.
+ *
+ * The reference (Kotstantinovskiy/SonicDiffusionBayesLab) is pure Python over diffusers and has
+ * no FFI of its own; each entry point below names the reference call site it replaces.  The
+ * reference-side binding a maintainer would add (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / C++ types.
+ *   - every function returns 0 on success, a negative code on failure; the message is available
+ *     through sd_last_error() (thread-local).  No exception crosses the ABI.
+ *   - `stream` is a hipStream_t passed as void*; work is only ever enqueued on that stream and
+ *     the library never synchronises the device inside a forward/step call.
+ *   - device buffers handed in are BORROWED for the duration of the call; the caller (PyTorch in
+ *     this repo) owns all I/O tensors and the workspace.  UNet weights are owned by the handle.
+ *   - activations are bf16 NHWC inside the library; latents / noise predictions cross the ABI as
+ *     fp32 NCHW, exactly the tensors the reference loop holds (src/models.py:173-182,227-261).
+ */
+#ifndef SD_HIP_H
+#define SD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sd_unet sd_unet;
+
+/* diffusers UNet2DConditionModel config subset used by SD-1.5 */
+typedef struct sd_unet_config {
+    int sample_size;             /* latent H = W (64 for 512x512) */
+    int in_channels;             /* 4 */
+    int out_channels;            /* 4 */
+    int num_levels;              /* 4 */
+    int block_out_channels[8];   /* 320,640,1280,1280 */
+    int layers_per_block;        /* 2 */
+    int attn_levels[8];          /* 1,1,1,0 : level carries Transformer2DModel blocks */
+    int cross_attention_dim;     /* 768 */
+    int num_heads;               /* 8 (diffusers attention_head_dim=8 is used as head COUNT) */
+    int norm_num_groups;         /* 32 */
+    float norm_eps;              /* 1e-5 */
+    int context_len;             /* 77 */
+} sd_unet_config;
+
+const char* sd_last_error(void);
+int sd_abi_version(void);
+
+/* ---- UNet handle: replaces `self.unet` of StableDiffusionPipeline (src/models.py:227-235) ---- */
+int sd_unet_create(const sd_unet_config* cfg, sd_unet** out);
+void sd_unet_destroy(sd_unet* u);
+
+/* Parameters use the diffusers state_dict names and layouts (conv OIHW, linear [out,in]), fp32 on
+ * the HOST; the library repacks (OHWI bf16, fused QKV, GEGLU interleave ...) and uploads them in
+ * sd_unet_finalize().  Replaces `from_pretrained(...).to(device)` for the UNet
+ * (src/experiments/base_experiment.py:55-64). */
+int sd_unet_num_params(const sd_unet* u);
+int sd_unet_param_info(const sd_unet* u, int index, char* name, int name_cap, long long shape[4], int* ndim);
+int sd_unet_load_param(sd_unet* u, const char* name, const float* host_data, long long numel);
+int sd_unet_finalize(sd_unet* u);
+
+/* Workspace the caller must provide for a given UNet batch (2*B with CFG).  `cache_branch_id`
+ * < 0 disables the DeepCache plan; >= 0 reserves the cached tensors of that branch
+ * (DeepCacheSDHelper.set_params, src/experiments/deep_cache.py:25-28). The SAME workspace must be
+ * passed to set_context and to every forward of one sampling run. */
+long long sd_unet_workspace_bytes(sd_unet* u, int unet_batch, int cache_branch_id);
+
+/* Prompt conditioning: device fp32 [unet_batch, context_len, cross_attention_dim]
+ * (`prompt_embeds` after the CFG concat, src/models.py:154-155).  Projects K/V of all
+ * cross-attention layers once -- they are step-invariant. */
+int sd_unet_set_context(sd_unet* u, void* stream, const float* encoder_hidden_states, int unet_batch,
+                        int cache_branch_id, void* workspace, long long workspace_bytes);
+
+enum { SD_CACHE_OFF = 0, SD_CACHE_FULL_AND_STORE = 1, SD_CACHE_SKIP = 2 };
+
+/* eps = UNet(latent_model_input, t, encoder_hidden_states)  (src/models.py:217-235).
+ * `latents` is fp32 NCHW [latent_batch,4,H,W]; with unet_batch = 2*latent_batch the CFG
+ * duplication `torch.cat([latents]*2)` (src/models.py:217) is fused into conv_in.
+ * `eps_out` is fp32 NCHW [unet_batch,4,H,W].  cache_mode selects the DeepCache plan
+ * (full step that refreshes the cache / skip step that reuses it). */
+int sd_unet_forward(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                    float timestep, float* eps_out, void* workspace, long long workspace_bytes, int cache_mode,
+                    int cache_branch_id);
+
+/* Debug/parity hook: copy a named intermediate (bf16 NHWC) of the LAST full forward into `out`
+ * as fp32; names: "conv_in", "down0".."down3", "mid", "up0".."up3".  Synchronises the stream. */
+int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host_out, long long numel,
+                         void* workspace, int unet_batch, int cache_branch_id);
+
+/* ---- fused CFG combine + scheduler.step (src/models.py:238-261; src/schedulers.py:98-187) ----
+ *   eps   = cfg ? eps[0:n] + guidance*(eps[n:2n]-eps[0:n]) : eps[0:n]
+ *   prev  = coef[0]*x + coef[1]*eps + coef[2]*m1 + coef[3]*m2 + coef[4]*noise
+ *   y2    = coef[5]*x + coef[6]*eps      (x0_pred / LCM "denoised"), optional
+ *   m_out = coef[7]*x + coef[8]*eps      (multistep history entry), optional
+ * One launch serves DDIM, DPM-Solver / DPM-Solver++ (orders 1-3) and LCM; the host computes the
+ * scalar coefficients from its sigma tables, so the kernel needs no host sync. */
+int sd_sched_step(void* stream, const float* eps, int cfg, float guidance, const float* x, const float* m1,
+                  const float* m2, const float* noise, float* prev, float* y2, float* m_out, const float coef[9],
+                  long long n);
+
+/* ---- operator-level entry points (each is one hot kernel; used by the parity tests) ----------- */
+/* C[M,N] = [X|X2][M,K] . W[N,K]^T + bias + bias2 + R ; epi=1: GEGLU on interleaved W (N -> N/2) */
+int sd_op_gemm(void* stream, const void* X, long long ldx, const void* X2, long long ldx2, int K1, const void* W,
+               const float* bias, const float* bias2, const void* R, long long ldr, void* C, long long ldc, int M,
+               int N, int K, int epi);
+/* NHWC 3x3 conv, pad 1, stride 1|2, optional fused nearest-2x upsample; W is [Cout][3][3][Cin] bf16 */
+int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2, const void* R,
+                  void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample);
+int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                    const float* beta, void* y, int B, int HW, int groups, float eps, int silu);
+int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows, int C,
+                    float eps);
+int sd_op_attention(void* stream, const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                    long long ldv, void* O, long long ldo, int B, int heads, int Nq, int Nk, int D, float scale);
+int sd_op_conv_in(void* stream, const float* x, int Bsrc, const float* Wt, const float* bias, void* y, int B, int H,
+                  int W, int Cin, int Cout);
+int sd_op_conv_out(void* stream, const void* x, const void* Wp, const float* bias, float* y, int B, int H, int W,
+                   int Cin, int Cout);
+int sd_op_time_embedding(void* stream, float t, const void* W1, const float* b1, const void* W2, const float* b2,
+                         float* scratch, float* temb, int dim_in, int dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_HIP_H */

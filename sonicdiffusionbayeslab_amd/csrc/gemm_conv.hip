@@ -1,0 +1,252 @@
+// bf16 MFMA GEMM and implicit-GEMM 3x3 convolution for gfx950.
+//
+//   C[M,N] = X[M,K] . W[N,K]^T  (+bias +bias2 +residual | GEGLU)
+//
+// * X rows are either plain matrix rows (GEMM; optionally two K-segments from two tensors =
+//   a channel concat that is never materialised) or NHWC pixels gathered on the fly for a 3x3
+//   convolution (stride 1/2, optional fused nearest-2x upsample); K = 9*Cin ordered tap-major.
+// * Tiles are staged global -> LDS with 16-byte `global_load_lds` (no VGPR round trip), double
+//   buffered, one barrier per 64-deep K tile.  LDS rows are 128 B (64 bf16) with the 16-byte
+//   chunk index XOR-swizzled by (row & 7) -- applied on the per-lane SOURCE address, LDS stays
+//   lane-linear -- so the ds_read_b128 fragment reads are bank-conflict free.
+// * Out-of-range rows (M/N tails, conv zero padding) read a zero page instead of branching.
+// * MFMA v_mfma_f32_16x16x32_bf16 with W as the A operand: a lane then owns 4 consecutive
+//   output columns of one row, i.e. one 8-byte packed bf16 store per 16x16 tile.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int AMODE_GEMM = 0;
+constexpr int AMODE_CONV = 1;
+constexpr int EPI_STD = 0;
+constexpr int EPI_GEGLU = 1;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int XI = BM / 8, WI = BN / 8;  // 1-KiB glds wave-instructions per tile
+    static_assert(XI % NW == 0 && WI % NW == 0, "tile rows must split evenly over waves");
+    constexpr int XPW = XI / NW, WPW = WI / NW;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(EPI != EPI_GEGLU || (TN % 2 == 0), "GEGLU pairs 16-col tiles");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware tile order: blocks that share an XCD (same blockIdx % 8) get consecutive tiles,
+    // n fastest, so the X panel of one m-tile is re-read from that XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-lane source descriptors -------------------------------------------------
+    const int lrow8 = lane >> 3;                 // row inside an 8-row glds piece
+    const int gch = (lane & 7) ^ lrow8;          // global 16-B chunk this lane fetches (swizzle)
+    const char* zero = (const char*)p.zero_page;
+
+    int xrow[XPW];        // GEMM: global row or -1.  CONV: batch pixel base or -1
+    int xoy[XPW], xox[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int inst = wave + i * NW;
+        const int m = m0 + inst * 8 + lrow8;
+        if (AMODE == AMODE_GEMM) {
+            xrow[i] = m < p.M ? m : -1;
+            xoy[i] = xox[i] = 0;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            xrow[i] = m < p.M ? b * p.Hin * p.Win : -1;
+            xoy[i] = oy * p.stride - 1;
+            xox[i] = ox * p.stride - 1;
+        }
+    }
+    const bf16_t* wsrc[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int inst = wave + i * NW;
+        const int n = n0 + inst * 8 + lrow8;
+        wsrc[i] = n < p.N ? p.W + (long)n * p.K + gch * 8 : nullptr;
+    }
+    const int cpt = (AMODE == AMODE_CONV) ? p.Cin / 64 : 1;  // K tiles per tap
+    const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
+
+    auto stage = [&](int kt, int buf) {
+        char* xs = smem + buf * STAGE_BYTES;
+        char* ws = xs + BM * 128;
+        const int k0 = kt * 64;
+        if (AMODE == AMODE_GEMM) {
+            const bool seg2 = k0 >= p.K1;
+            const bf16_t* base = seg2 ? p.X2 : p.X;
+            const long ld = seg2 ? p.ldx2 : p.ldx;
+            const int kk = (seg2 ? k0 - p.K1 : k0) + gch * 8;
+#pragma unroll
+            for (int i = 0; i < XPW; ++i) {
+                const int inst = wave + i * NW;
+                const void* src = xrow[i] >= 0 ? (const void*)(base + (long)xrow[i] * ld + kk) : (const void*)zero;
+                glds16(src, xs + inst * 1024);
+            }
+        } else {
+            const int tap = kt / cpt, cs = kt - tap * cpt;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int coff = cs * 64 + gch * 8;
+#pragma unroll
+            for (int i = 0; i < XPW; ++i) {
+                const int inst = wave + i * NW;
+                const int ty = xoy[i] + dy, tx = xox[i] + dx;
+                const bool ok = xrow[i] >= 0 && ty >= 0 && ty < Hv && tx >= 0 && tx < Wv;
+                const int iy = ty >> p.up, ix = tx >> p.up;
+                const void* src = ok ? (const void*)(p.X + ((long)(xrow[i] + iy * p.Win + ix)) * p.Cin + coff)
+                                     : (const void*)zero;
+                glds16(src, xs + inst * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int inst = wave + i * NW;
+            const void* src = wsrc[i] ? (const void*)(wsrc[i] + k0) : (const void*)zero;
+            glds16(src, ws + inst * 1024);
+        }
+    };
+
+    // ---- main loop ---------------------------------------------------------------------
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int swz[2] = {((lq) ^ (lane & 7)) << 4, ((4 + lq) ^ (lane & 7)) << 4};
+    const int xoff = (wm * WTM + lrow) * 128;
+    const int woff = BM * 128 + (wn * WTN + lrow) * 128;
+
+    const int KT = p.K / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        const char* sb = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[TM], wf[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8*)(sb + woff + t * 2048 + swz[ks]);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns columns n..n+3 of row m for each 16x16 tile ----------------
+    if (EPI == EPI_STD) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wn * WTN + a * 16 + lq * 4;
+            if (n >= p.N) continue;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *(const f32x4*)(p.bias + n);
+            if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * WTM + b * 16 + lrow;
+                if (m >= p.M) continue;
+                f32x4 v = acc[a][b] + bv;
+                if (p.R) {
+                    const u32x2 r = *(const u32x2*)(p.R + (long)m * p.ldr + n);
+                    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+                }
+                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+            }
+        }
+    } else {
+        // GEGLU: weight rows were packed so that every 32-column group is [16 value | 16 gate]
+#pragma unroll
+        for (int a = 0; a < TN; a += 2) {
+            const int n = n0 + wn * WTN + a * 16;  // first packed column of the pair
+            if (n >= p.N) continue;
+            const int no = (n >> 1) + lq * 4;      // output column
+            f32x4 bva = {0.f, 0.f, 0.f, 0.f}, bvg = bva;
+            if (p.bias) {
+                bva = *(const f32x4*)(p.bias + n + lq * 4);
+                bvg = *(const f32x4*)(p.bias + n + 16 + lq * 4);
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * WTM + b * 16 + lrow;
+                if (m >= p.M) continue;
+                const f32x4 va = acc[a][b] + bva, vg = acc[a + 1][b] + bvg;
+                u32x2 o = {pack2bf(va[0] * gelu_erf_f(vg[0]), va[1] * gelu_erf_f(vg[1])),
+                           pack2bf(va[2] * gelu_erf_f(vg[2]), va[3] * gelu_erf_f(vg[3]))};
+                *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
+int launch(const GemmArgs& a0, hipStream_t stream) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int grid = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, stream, a);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
+    SD_REQUIRE(a.K % 64 == 0 && a.K >= 64, "gemm: K=%d must be a positive multiple of 64", a.K);
+    SD_REQUIRE(a.N % 4 == 0, "gemm: N=%d must be a multiple of 4", a.N);
+    SD_REQUIRE(a.K1 % 64 == 0 && a.K1 <= a.K, "gemm: K1=%d must be a multiple of 64 and <= K", a.K1);
+    SD_REQUIRE(a.K1 == a.K || a.X2 != nullptr, "gemm: second K segment needs X2");
+    SD_REQUIRE(a.M > 0 && a.N > 0, "gemm: empty problem");
+    SD_REQUIRE(a.zero_page != nullptr, "gemm: zero page missing");
+    if (epi == EPI_GEGLU) {
+        SD_REQUIRE(a.N % 32 == 0, "geglu gemm: N=%d must be a multiple of 32", a.N);
+        return launch<128, 128, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
+    }
+    return launch<128, 160, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
+}
+
+int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
+    SD_REQUIRE(a.Cin % 64 == 0, "conv3x3: Cin=%d must be a multiple of 64", a.Cin);
+    SD_REQUIRE(a.K == 9 * a.Cin, "conv3x3: K must be 9*Cin");
+    SD_REQUIRE(a.N % 4 == 0, "conv3x3: Cout=%d must be a multiple of 4", a.N);
+    SD_REQUIRE(a.stride == 1 || a.stride == 2, "conv3x3: stride %d", a.stride);
+    SD_REQUIRE(!(a.up && a.stride != 1), "conv3x3: upsample needs stride 1");
+    SD_REQUIRE(a.zero_page != nullptr, "conv3x3: zero page missing");
+    const int hv = a.Hin << a.up, wv = a.Win << a.up;
+    SD_REQUIRE(a.Hout == (hv + 2 - 3) / a.stride + 1 && a.Wout == (wv + 2 - 3) / a.stride + 1,
+               "conv3x3: output size %dx%d inconsistent with input %dx%d stride %d up %d", a.Hout, a.Wout,
+               a.Hin, a.Win, a.stride, a.up);
+    SD_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "conv3x3: M not a multiple of Hout*Wout");
+    return launch<128, 160, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
+}

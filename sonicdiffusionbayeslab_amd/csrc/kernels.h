@@ -1,0 +1,80 @@
+// Internal launcher interface shared by the kernel translation units and unet.hip.
+// Every launcher validates its operand shapes on the host BEFORE launching (a faulting kernel
+// can take the whole GPU host down), enqueues on the caller's stream only, never synchronises,
+// and returns 0 / negative with the message available through sd_last_error().
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const bf16_t* X = nullptr;   // GEMM: [M, K1] rows (ldx);  CONV: NHWC input [B, Hin, Win, Cin]
+    long ldx = 0;
+    const bf16_t* X2 = nullptr;  // optional second K segment [M, K-K1] (channel concat), GEMM only
+    long ldx2 = 0;
+    int K1 = 0;                  // split point (== K when there is no second segment)
+    const bf16_t* W = nullptr;   // [N, K] row-major (conv: K = tap*Cin + cin)
+    const float* bias = nullptr;   // [N] fp32, optional
+    const float* bias2 = nullptr;  // [N] fp32, optional (time-embedding projection)
+    const bf16_t* R = nullptr;     // residual [M, ldr], optional
+    long ldr = 0;
+    bf16_t* C = nullptr;           // output [M, ldc]
+    long ldc = 0;
+    int M = 0, N = 0, K = 0;
+    // conv geometry
+    int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, stride = 1, up = 0;
+    const void* zero_page = nullptr;  // >= 16 zero bytes in device memory
+    int tiles_m = 0, tiles_n = 0;     // filled by the launcher
+};
+
+int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu*/, hipStream_t stream);
+int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
+
+// GroupNorm over NHWC (optionally a two-tensor channel concat) -> bf16 [B, HW, C1+C2]
+struct GroupNormArgs {
+    const bf16_t* x1 = nullptr; int C1 = 0;
+    const bf16_t* x2 = nullptr; int C2 = 0;   // optional
+    const float* gamma = nullptr; const float* beta = nullptr;  // [C1+C2]
+    bf16_t* y = nullptr;
+    float* partial = nullptr;   // workspace [B, nsplit, groups, 2] fp32
+    int B = 0, HW = 0, groups = 32, nsplit = 0;
+    float eps = 1e-5f;
+    int silu = 0;
+};
+int sd_groupnorm_nsplit(int B, int HW);
+int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream);
+
+int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
+                        float eps, hipStream_t stream);
+
+struct AttnArgs {
+    const bf16_t* Q = nullptr; long ldq = 0;  // [B, Nq, heads*D] rows with stride ldq
+    const bf16_t* K = nullptr; long ldk = 0;  // [B, Nk, ...]
+    const bf16_t* V = nullptr; long ldv = 0;
+    bf16_t* O = nullptr; long ldo = 0;
+    int B = 0, heads = 0, Nq = 0, Nk = 0, D = 0;
+    float scale = 0.f;
+};
+int sd_launch_attention(const AttnArgs& a, hipStream_t stream);
+
+// y[n] = sum_k W[n,k] * act_in(x[k]) + b[n]   (M = 1 path: timestep embedding MLP + projections)
+int sd_launch_gemv(const float* x, const bf16_t* W, const float* b, float* y, int N, int K, int silu_in,
+                   hipStream_t stream);
+int sd_launch_timestep_sinusoid(float t, float* out, int dim, hipStream_t stream);
+int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
+
+// conv_in: NCHW fp32 latents [Bsrc,4,H,W] (batch index taken modulo Bsrc: CFG duplication is
+// fused) -> NHWC bf16 [B,H,W,Cout]
+int sd_launch_conv_in(const float* x, int Bsrc, const float* Wt /*[Cin*9][Cout] fp32*/, const float* bias,
+                      bf16_t* y, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+// conv_out: NHWC bf16 [B,H,W,Cin] -> NCHW fp32 [B,Cout,H,W]  (Cout <= 4)
+int sd_launch_conv_out(const bf16_t* x, const bf16_t* Wp /*[Cout][9][Cin]*/, const float* bias, float* y, int B,
+                       int H, int W, int Cin, int Cout, hipStream_t stream);
+
+// fused CFG combine + linear multistep scheduler update (DDIM / DPM-Solver(++) / LCM)
+struct StepCoef {
+    float px, pe, p1, p2, pn;  // prev = px*x + pe*eps + p1*m1 + p2*m2 + pn*noise
+    float yx, ye;              // y2   = yx*x + ye*eps           (x0_pred / denoised)
+    float mx, me;              // m0   = mx*x + me*eps           (history entry)
+};
+int sd_launch_sched_step(const float* eps, int cfg, float guidance, const float* x, const float* m1,
+                         const float* m2, const float* noise, float* prev, float* y2, float* m_out,
+                         StepCoef c, long n, hipStream_t stream);

@@ -1,0 +1,205 @@
+// GroupNorm(+SiLU) over NHWC activations and LayerNorm over token rows, gfx950.
+// Both are HBM-bound: every access is a 16-byte (8 x bf16) vector, rows are contiguous, and a
+// thread keeps a FIXED 8-channel chunk so its per-channel scale/shift live in registers.
+// GroupNorm is two launches: (1) deterministic partial sums per (batch, pixel-split, group),
+// (2) finalise + normalise (+SiLU).  A two-tensor channel concat is read in place and written
+// as one contiguous tensor (the only place the up-path concat is ever materialised).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct GnGeom {
+    int nchunks, rows_par, threads, cpg, C;
+};
+
+__host__ __device__ inline GnGeom gn_geom(int C, int groups) {
+    GnGeom g;
+    g.C = C;
+    g.nchunks = C / 8;
+    g.rows_par = g.nchunks >= 256 ? 1 : 256 / g.nchunks;
+    const int act = g.rows_par * g.nchunks;
+    g.threads = (act + 63) / 64 * 64;
+    g.cpg = C / groups;
+    return g;
+}
+
+__device__ __forceinline__ const bf16_t* gn_src(const GroupNormArgs& a, long pix, int c0) {
+    return c0 < a.C1 ? a.x1 + pix * a.C1 + c0 : a.x2 + pix * a.C2 + (c0 - a.C1);
+}
+
+__global__ void gn_stats_kernel(const GroupNormArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sh = (float4*)smem;
+    const GnGeom g = gn_geom(a.C1 + a.C2, a.groups);
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const bool active = tid < g.rows_par * g.nchunks;
+    const int prow = tid / g.nchunks, ch = tid - prow * g.nchunks;
+    const int c0 = ch * 8;
+    const int g0 = c0 / g.cpg;
+    const int nb = min(8, (g0 + 1) * g.cpg - c0);  // elements of this chunk that belong to g0
+    const int per = (a.HW + a.nsplit - 1) / a.nsplit;
+    const int pbeg = split * per, pend = min(a.HW, pbeg + per);
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    if (active) {
+        for (int p = pbeg + prow; p < pend; p += g.rows_par) {
+            const u32x4 v = *(const u32x4*)gn_src(a, (long)b * a.HW + p, c0);
+            float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]),
+                          bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < nb) { s0 += f[j]; q0 += f[j] * f[j]; }
+                else        { s1 += f[j]; q1 += f[j] * f[j]; }
+            }
+        }
+    }
+    sh[tid] = make_float4(s0, q0, s1, q1);
+    __syncthreads();
+    if (tid < a.groups) {
+        float s = 0.f, q = 0.f;
+        const int nact = g.rows_par * g.nchunks;
+        for (int t = 0; t < nact; ++t) {       // fixed order -> bitwise reproducible
+            const int tc0 = (t % g.nchunks) * 8;
+            const int tg0 = tc0 / g.cpg, tg1 = (tc0 + 7) / g.cpg;
+            const float4 v = sh[t];
+            if (tg0 == tid) { s += v.x; q += v.y; }
+            if (tg1 == tid && tg1 != tg0) { s += v.z; q += v.w; }
+        }
+        float* out = a.partial + (((long)b * a.nsplit + split) * a.groups + tid) * 2;
+        out[0] = s;
+        out[1] = q;
+    }
+}
+
+__global__ void gn_apply_kernel(const GroupNormArgs a) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const GnGeom g = gn_geom(a.C1 + a.C2, a.groups);
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x, b = blockIdx.y;
+    if (tid < a.groups) {
+        float s = 0.f, q = 0.f;
+        const float* pp = a.partial + ((long)b * a.nsplit * a.groups + tid) * 2;
+        for (int i = 0; i < a.nsplit; ++i) { s += pp[(long)i * a.groups * 2]; q += pp[(long)i * a.groups * 2 + 1]; }
+        const float cnt = (float)a.HW * (float)g.cpg;
+        const float mean = s / cnt;
+        const float var = fmaxf(q / cnt - mean * mean, 0.f);
+        mean_s[tid] = mean;
+        rstd_s[tid] = rsqrtf(var + a.eps);
+    }
+    __syncthreads();
+    const bool active = tid < g.rows_par * g.nchunks;
+    if (!active) return;
+    const int prow = tid / g.nchunks, ch = tid - prow * g.nchunks;
+    const int c0 = ch * 8;
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j, gi = c / g.cpg;
+        sc[j] = rstd_s[gi] * a.gamma[c];
+        sf[j] = a.beta[c] - mean_s[gi] * sc[j];
+    }
+    const int per = (a.HW + a.nsplit - 1) / a.nsplit;
+    const int pbeg = split * per, pend = min(a.HW, pbeg + per);
+    for (int p = pbeg + prow; p < pend; p += g.rows_par) {
+        const long pix = (long)b * a.HW + p;
+        const u32x4 v = *(const u32x4*)gn_src(a, pix, c0);
+        float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]),
+                      bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f[j] = f[j] * sc[j] + sf[j];
+            if (a.silu) f[j] = silu_f(f[j]);
+        }
+        u32x4 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+        *(u32x4*)(a.y + pix * g.C + c0) = o;
+    }
+}
+
+// one wave per token row; up to 3 chunks of 8 channels per lane (C <= 1536)
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunks = C >> 3;
+    const bf16_t* xr = x + (long)row * C;
+    float f[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            const u32x4 v = *(const u32x4*)(xr + ch * 8);
+            f[i][0] = bflo(v[0]); f[i][1] = bfhi(v[0]); f[i][2] = bflo(v[1]); f[i][3] = bfhi(v[1]);
+            f[i][4] = bflo(v[2]); f[i][5] = bfhi(v[2]); f[i][6] = bflo(v[3]); f[i][7] = bfhi(v[3]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[i][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    bf16_t* yr = y + (long)row * C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            const f32x4 g0 = *(const f32x4*)(gamma + ch * 8), g1 = *(const f32x4*)(gamma + ch * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + ch * 8), b1 = *(const f32x4*)(beta + ch * 8 + 4);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+                o[j + 4] = (f[i][j + 4] - mean) * rstd * g1[j] + b1[j];
+            }
+            u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+            *(u32x4*)(yr + ch * 8) = ov;
+        }
+    }
+}
+
+}  // namespace
+
+int sd_groupnorm_nsplit(int B, int HW) {
+    (void)B;
+    int n = HW / 64;
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
+    const int C = a.C1 + a.C2;
+    SD_REQUIRE(a.x1 && a.y && a.gamma && a.beta && a.partial, "groupnorm: null operand");
+    SD_REQUIRE(a.C1 % 8 == 0 && a.C2 % 8 == 0 && (a.C2 == 0 || a.x2), "groupnorm: C1=%d C2=%d must be multiples of 8", a.C1, a.C2);
+    SD_REQUIRE(a.groups > 0 && a.groups <= 64 && C % a.groups == 0 && C / a.groups >= 8,
+               "groupnorm: C=%d groups=%d needs C/groups >= 8", C, a.groups);
+    SD_REQUIRE(a.nsplit >= 1 && a.nsplit <= a.HW && a.B > 0 && a.HW > 0, "groupnorm: bad split %d for HW=%d", a.nsplit, a.HW);
+    const GnGeom g = gn_geom(C, a.groups);
+    SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
+    dim3 grid(a.nsplit, a.B);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), g.threads * sizeof(float4), stream, a);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, a);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
+                        float eps, hipStream_t stream) {
+    SD_REQUIRE(x && y && gamma && beta, "layernorm: null operand");
+    SD_REQUIRE(C % 8 == 0 && C > 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
+    SD_REQUIRE(rows > 0, "layernorm: no rows");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}

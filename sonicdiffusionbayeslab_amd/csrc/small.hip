@@ -1,0 +1,216 @@
+// Small gfx950 kernels around the UNet body: timestep embedding (sinusoid + M=1 GEMV chain),
+// conv_in (NCHW fp32 latents -> NHWC bf16, CFG batch duplication fused), conv_out (NHWC bf16 ->
+// NCHW fp32 noise prediction) and the fused CFG-combine + scheduler.step update.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---- timestep sinusoid: flip_sin_to_cos=True, freq_shift=0 -> [cos(t f_k) | sin(t f_k)] ----
+__global__ void sinusoid_kernel(float t, float* __restrict__ out, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= dim) return;
+    const int k = i < half ? i : i - half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+    const float e = t * f;
+    out[i] = i < half ? cosf(e) : sinf(e);
+}
+
+// ---- GEMV: one wave per output row --------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
+                                                   const float* __restrict__ b, float* __restrict__ y, int N, int K,
+                                                   int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const bf16_t* wr = W + (long)n * K;
+    float acc = 0.f;
+    for (int ch = lane; ch < K / 8; ch += 64) {
+        const u32x4 w = *(const u32x4*)(wr + ch * 8);
+        const f32x4 x0 = *(const f32x4*)(x + ch * 8), x1 = *(const f32x4*)(x + ch * 8 + 4);
+        float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        if (silu_in) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = silu_f(xv[j]);
+        }
+        acc += bflo(w[0]) * xv[0] + bfhi(w[0]) * xv[1] + bflo(w[1]) * xv[2] + bfhi(w[1]) * xv[3] +
+               bflo(w[2]) * xv[4] + bfhi(w[2]) * xv[5] + bflo(w[3]) * xv[6] + bfhi(w[3]) * xv[7];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[n] = acc + (b ? b[n] : 0.f);
+}
+
+// ---- conv_in: 3x3, Cin = 4, one block per output row, thread = 2 output channels ------------
+template <int CIN>
+__global__ void conv_in_kernel(const float* __restrict__ x, int Bsrc, const float* __restrict__ Wt,
+                               const float* __restrict__ bias, bf16_t* __restrict__ y, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* patch = (float*)smem;  // [CIN][3][W+2]
+    const int yrow = blockIdx.x, b = blockIdx.y;
+    const int bs = b % Bsrc;
+    const int tid = threadIdx.x;
+    const int PW = W + 2;
+    for (int i = tid; i < CIN * 3 * PW; i += blockDim.x) {
+        const int ci = i / (3 * PW), rem = i - ci * 3 * PW;
+        const int dy = rem / PW, px = rem - dy * PW;
+        const int iy = yrow + dy - 1, ix = px - 1;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long)bs * CIN + ci) * H + iy) * W + ix];
+        patch[i] = v;
+    }
+    __syncthreads();
+    const int co = tid * 2;
+    if (co >= Cout) return;
+    float w0[CIN * 9], w1[CIN * 9];
+#pragma unroll
+    for (int k = 0; k < CIN * 9; ++k) {
+        w0[k] = Wt[k * Cout + co];
+        w1[k] = Wt[k * Cout + co + 1];
+    }
+    const float b0 = bias[co], b1 = bias[co + 1];
+    bf16_t* yr = y + (((long)b * H + yrow) * W) * Cout + co;
+    for (int ox = 0; ox < W; ++ox) {
+        float a0 = b0, a1 = b1;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = patch[(ci * 3 + dy) * PW + ox + dx];
+                    a0 += v * w0[ci * 9 + dy * 3 + dx];
+                    a1 += v * w1[ci * 9 + dy * 3 + dx];
+                }
+        *(unsigned*)(yr + (long)ox * Cout) = pack2bf(a0, a1);
+    }
+}
+
+// ---- conv_out: 3x3, Cout <= 4, one wave per output pixel ------------------------------------
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wp,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                       int H, int W, int Cin, int Cout) {
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long npix = (long)B * H * W;
+    if (pix >= npix) return;
+    const int b = (int)(pix / (H * W));
+    const int rem = (int)(pix - (long)b * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    const int nchunks = Cin / 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = lane; ch < nchunks; ch += 64) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const u32x4 v = *(const u32x4*)(x + (((long)b * H + iy) * W + ix) * Cin + ch * 8);
+            const float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]),
+                                bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co >= Cout) break;
+                const u32x4 w = *(const u32x4*)(Wp + ((long)co * 9 + tap) * Cin + ch * 8);
+                acc[co] += f[0] * bflo(w[0]) + f[1] * bfhi(w[0]) + f[2] * bflo(w[1]) + f[3] * bfhi(w[1]) +
+                           f[4] * bflo(w[2]) + f[5] * bfhi(w[2]) + f[6] * bflo(w[3]) + f[7] * bfhi(w[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) acc[co] = wave_sum(acc[co]);
+    const float mine = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+    if (lane < Cout) y[(((long)b * Cout + lane) * H + oy) * W + ox] = mine + bias[lane];
+}
+
+// ---- fused CFG + scheduler update ---------------------------------------------------------
+__global__ void sched_step_kernel(const float* __restrict__ eps, int cfg, float guidance,
+                                  const float* __restrict__ x, const float* __restrict__ m1,
+                                  const float* __restrict__ m2, const float* __restrict__ noise,
+                                  float* __restrict__ prev, float* __restrict__ y2, float* __restrict__ m_out,
+                                  StepCoef c, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 e = ((const f32x4*)eps)[i];
+    if (cfg) {
+        const f32x4 et = ((const f32x4*)eps)[i + n4];
+        e = e + guidance * (et - e);
+    }
+    const f32x4 xv = ((const f32x4*)x)[i];
+    f32x4 p = c.px * xv + c.pe * e;
+    if (m1) p += c.p1 * ((const f32x4*)m1)[i];
+    if (m2) p += c.p2 * ((const f32x4*)m2)[i];
+    if (noise) p += c.pn * ((const f32x4*)noise)[i];
+    if (y2) ((f32x4*)y2)[i] = c.yx * xv + c.ye * e;
+    if (m_out) ((f32x4*)m_out)[i] = c.mx * xv + c.me * e;
+    ((f32x4*)prev)[i] = p;
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = ((const f32x4*)src)[i];
+    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    ((u32x2*)dst)[i] = o;
+}
+
+}  // namespace
+
+int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream) {
+    SD_REQUIRE(src && dst && n > 0 && n % 4 == 0, "f32_to_bf16: n=%ld must be a positive multiple of 4", n);
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, src, dst, n4);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_timestep_sinusoid(float t, float* out, int dim, hipStream_t stream) {
+    SD_REQUIRE(out && dim > 0 && dim % 2 == 0, "sinusoid: bad dim %d", dim);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_gemv(const float* x, const bf16_t* W, const float* b, float* y, int N, int K, int silu_in,
+                   hipStream_t stream) {
+    SD_REQUIRE(x && W && y, "gemv: null operand");
+    SD_REQUIRE(K % 8 == 0 && N > 0, "gemv: K=%d must be a multiple of 8", K);
+    hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, W, b, y, N, K, silu_in);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_conv_in(const float* x, int Bsrc, const float* Wt, const float* bias, bf16_t* y, int B, int H, int W,
+                      int Cin, int Cout, hipStream_t stream) {
+    SD_REQUIRE(x && Wt && bias && y, "conv_in: null operand");
+    SD_REQUIRE(Cin == 4, "conv_in: Cin=%d (only 4 is built)", Cin);
+    SD_REQUIRE(Cout % 2 == 0 && Cout / 2 <= 1024, "conv_in: Cout=%d", Cout);
+    SD_REQUIRE(Bsrc > 0 && B > 0 && B % Bsrc == 0, "conv_in: batch %d not a multiple of source batch %d", B, Bsrc);
+    const int threads = (Cout / 2 + 63) / 64 * 64;
+    const size_t smem = (size_t)Cin * 3 * (W + 2) * sizeof(float);
+    hipLaunchKernelGGL((conv_in_kernel<4>), dim3(H, B), dim3(threads), smem, stream, x, Bsrc, Wt, bias, y, H, W, Cout);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_conv_out(const bf16_t* x, const bf16_t* Wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                       int Cout, hipStream_t stream) {
+    SD_REQUIRE(x && Wp && bias && y, "conv_out: null operand");
+    SD_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "conv_out: Cin=%d Cout=%d", Cin, Cout);
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, stream, x, Wp, bias, y, B, H, W,
+                       Cin, Cout);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_sched_step(const float* eps, int cfg, float guidance, const float* x, const float* m1,
+                         const float* m2, const float* noise, float* prev, float* y2, float* m_out, StepCoef c,
+                         long n, hipStream_t stream) {
+    SD_REQUIRE(eps && x && prev, "sched_step: null operand");
+    SD_REQUIRE(n > 0 && n % 4 == 0, "sched_step: n=%ld must be a positive multiple of 4", n);
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, eps, cfg, guidance,
+                       x, m1, m2, noise, prev, y2, m_out, c, n4);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}

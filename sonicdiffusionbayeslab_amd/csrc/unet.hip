@@ -1,0 +1,968 @@
+// libsdhip host side: UNet handle (parameter packing, execution plan with lifetime-based
+// workspace assignment, DeepCache plan filtering) and the C ABI declared in include/sd_hip.h.
+//
+// Replaces diffusers' UNet2DConditionModel.forward as called at src/models.py:227-235 of the
+// reference, plus DeepCacheSDHelper's skip path (src/experiments/deep_cache.py:24-29) and the
+// CFG + scheduler.step glue (src/models.py:238-261).
+#include "../../include/sd_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void sd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sd_last_error(void) { return g_err; }
+extern "C" int sd_abi_version(void) { return 1; }
+
+static void* g_zero_page = nullptr;
+static int ensure_zero_page() {
+    if (g_zero_page) return 0;
+    SD_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
+    SD_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t NOFF = (size_t)-1;
+constexpr int T_LATENTS = -2, T_EPS = -3;
+
+struct ParamSpec {
+    std::string name;
+    std::vector<long long> shape;
+    std::vector<float> data;
+    bool loaded = false;
+    long long numel() const {
+        long long n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct Wrap {  // one DeepCache-wrapped module enclosing an op
+    int type;  // 0 down, 1 mid, 2 up
+    int block_i, layer_i;
+};
+
+enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT };
+
+struct Op {
+    int kind = 0;
+    int x1 = -1, x2 = -1, r = -1, out = -1, aux = -1, b2t = -1;
+    size_t w = NOFF, b = NOFF, g = NOFF, be = NOFF;
+    long b2idx = 0;
+    int M = 0, N = 0, K = 0, K1 = 0, epi = 0;
+    int B = 0, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, stride = 1, up = 0;
+    int C1 = 0, C2 = 0, HW = 0, silu = 0, nsplit = 0;
+    float eps = 0.f;
+    int heads = 0, D = 0, Nq = 0, Nk = 0;
+    long ldq = 0, ldk = 0, ldv = 0, ldo = 0, qoff = 0, koff = 0, voff = 0;
+    int silu_in = 0;
+    int nwrap = 0;
+    Wrap wraps[3];
+};
+
+struct Tn {
+    size_t bytes = 0;
+    int def = -1, last = -1;
+    bool persistent = false;
+    size_t off = NOFF;
+};
+
+struct Plan {
+    int UB = 0, branch = -1;
+    std::vector<Tn> tensors;
+    std::vector<Op> ops;
+    std::vector<char> skipped;            // per op: skipped on a DeepCache skip step
+    std::vector<int> ctx_kv;              // tensor id of the [UB*L, 2C] K|V cache per cross-attn layer
+    std::vector<size_t> ctx_w;            // packed [2C, 768] weight offset per layer
+    std::vector<int> ctx_c;               // C per layer
+    int ctx_bf16 = -1;                    // bf16 copy of encoder_hidden_states
+    std::map<std::string, int> taps;
+    size_t total_bytes = 0;
+};
+
+}  // namespace
+
+struct sd_unet {
+    sd_unet_config cfg;
+    std::vector<ParamSpec> params;
+    std::unordered_map<std::string, int> pindex;
+    std::unordered_map<std::string, size_t> woff;  // packed item -> byte offset into dweights
+    std::vector<unsigned char> hblob;              // host staging of the packed blob
+    char* dweights = nullptr;
+    bool finalized = false;
+    bool debug_taps = false;
+    std::map<std::pair<int, int>, Plan> plans;
+    std::unordered_map<std::string, long> tproj_off;  // resnet prefix -> float index into tproj vector
+    long tproj_total = 0;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// parameter enumeration (diffusers state_dict names)
+// ---------------------------------------------------------------------------------------------
+struct Enum {
+    sd_unet* u;
+    void add(const std::string& n, std::vector<long long> shape) {
+        ParamSpec p;
+        p.name = n;
+        p.shape = std::move(shape);
+        u->pindex[n] = (int)u->params.size();
+        u->params.push_back(std::move(p));
+    }
+    void resnet(const std::string& p, int cin, int cout, int temb) {
+        add(p + "norm1.weight", {cin});
+        add(p + "norm1.bias", {cin});
+        add(p + "conv1.weight", {cout, cin, 3, 3});
+        add(p + "conv1.bias", {cout});
+        add(p + "time_emb_proj.weight", {cout, temb});
+        add(p + "time_emb_proj.bias", {cout});
+        add(p + "norm2.weight", {cout});
+        add(p + "norm2.bias", {cout});
+        add(p + "conv2.weight", {cout, cout, 3, 3});
+        add(p + "conv2.bias", {cout});
+        if (cin != cout) {
+            add(p + "conv_shortcut.weight", {cout, cin, 1, 1});
+            add(p + "conv_shortcut.bias", {cout});
+        }
+    }
+    void transformer(const std::string& p, int c, int ctx) {
+        add(p + "norm.weight", {c});
+        add(p + "norm.bias", {c});
+        add(p + "proj_in.weight", {c, c, 1, 1});
+        add(p + "proj_in.bias", {c});
+        const std::string t = p + "transformer_blocks.0.";
+        for (int i = 1; i <= 3; ++i) {
+            add(t + "norm" + std::to_string(i) + ".weight", {c});
+            add(t + "norm" + std::to_string(i) + ".bias", {c});
+        }
+        add(t + "attn1.to_q.weight", {c, c});
+        add(t + "attn1.to_k.weight", {c, c});
+        add(t + "attn1.to_v.weight", {c, c});
+        add(t + "attn1.to_out.0.weight", {c, c});
+        add(t + "attn1.to_out.0.bias", {c});
+        add(t + "attn2.to_q.weight", {c, c});
+        add(t + "attn2.to_k.weight", {c, ctx});
+        add(t + "attn2.to_v.weight", {c, ctx});
+        add(t + "attn2.to_out.0.weight", {c, c});
+        add(t + "attn2.to_out.0.bias", {c});
+        add(t + "ff.net.0.proj.weight", {8 * c, c});
+        add(t + "ff.net.0.proj.bias", {8 * c});
+        add(t + "ff.net.2.weight", {c, 4 * c});
+        add(t + "ff.net.2.bias", {c});
+        add(p + "proj_out.weight", {c, c, 1, 1});
+        add(p + "proj_out.bias", {c});
+    }
+};
+
+void enumerate_params(sd_unet* u) {
+    const sd_unet_config& c = u->cfg;
+    Enum e{u};
+    const int c0 = c.block_out_channels[0], temb = 4 * c0, nl = c.num_levels;
+    e.add("time_embedding.linear_1.weight", {temb, c0});
+    e.add("time_embedding.linear_1.bias", {temb});
+    e.add("time_embedding.linear_2.weight", {temb, temb});
+    e.add("time_embedding.linear_2.bias", {temb});
+    e.add("conv_in.weight", {c0, c.in_channels, 3, 3});
+    e.add("conv_in.bias", {c0});
+    int ch = c0;
+    std::vector<int> skip_ch{c0};
+    for (int i = 0; i < nl; ++i) {
+        const int co = c.block_out_channels[i];
+        const std::string bp = "down_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            e.resnet(bp + "resnets." + std::to_string(j) + ".", ch, co, temb);
+            ch = co;
+            if (c.attn_levels[i]) e.transformer(bp + "attentions." + std::to_string(j) + ".", co, c.cross_attention_dim);
+            skip_ch.push_back(co);
+        }
+        if (i < nl - 1) {
+            e.add(bp + "downsamplers.0.conv.weight", {co, co, 3, 3});
+            e.add(bp + "downsamplers.0.conv.bias", {co});
+            skip_ch.push_back(co);
+        }
+    }
+    e.resnet("mid_block.resnets.0.", ch, ch, temb);
+    e.transformer("mid_block.attentions.0.", ch, c.cross_attention_dim);
+    e.resnet("mid_block.resnets.1.", ch, ch, temb);
+    for (int i = 0; i < nl; ++i) {
+        const int lev = nl - 1 - i, co = c.block_out_channels[lev];
+        const std::string bp = "up_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            const int sc = skip_ch.back();
+            skip_ch.pop_back();
+            e.resnet(bp + "resnets." + std::to_string(j) + ".", ch + sc, co, temb);
+            ch = co;
+            if (c.attn_levels[lev]) e.transformer(bp + "attentions." + std::to_string(j) + ".", co, c.cross_attention_dim);
+        }
+        if (i < nl - 1) {
+            e.add(bp + "upsamplers.0.conv.weight", {co, co, 3, 3});
+            e.add(bp + "upsamplers.0.conv.bias", {co});
+        }
+    }
+    e.add("conv_norm_out.weight", {c0});
+    e.add("conv_norm_out.bias", {c0});
+    e.add("conv_out.weight", {c.out_channels, c0, 3, 3});
+    e.add("conv_out.bias", {c.out_channels});
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (host)
+// ---------------------------------------------------------------------------------------------
+inline unsigned short f32_to_bf16_host(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    u = u + 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+struct Packer {
+    sd_unet* u;
+    const std::vector<float>& P(const std::string& n) { return u->params[u->pindex.at(n)].data; }
+    size_t alloc(const std::string& key, size_t bytes) {
+        size_t off = (u->hblob.size() + 255) / 256 * 256;
+        u->hblob.resize(off + bytes);
+        u->woff[key] = off;
+        return off;
+    }
+    void f32(const std::string& n) {
+        const auto& d = P(n);
+        size_t off = alloc(n, d.size() * 4);
+        memcpy(u->hblob.data() + off, d.data(), d.size() * 4);
+    }
+    void bf16_same(const std::string& n) {
+        const auto& d = P(n);
+        size_t off = alloc(n, d.size() * 2);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+        for (size_t i = 0; i < d.size(); ++i) o[i] = f32_to_bf16_host(d[i]);
+    }
+    void conv3(const std::string& n, int O, int I) {  // OIHW -> OHWI
+        const auto& d = P(n);
+        size_t off = alloc(n, d.size() * 2);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+        for (int oc = 0; oc < O; ++oc)
+            for (int ic = 0; ic < I; ++ic)
+                for (int t = 0; t < 9; ++t)
+                    o[((size_t)oc * 9 + t) * I + ic] = f32_to_bf16_host(d[((size_t)oc * I + ic) * 9 + t]);
+    }
+    void concat_rows(const std::string& key, const std::vector<std::string>& names) {
+        size_t total = 0;
+        for (auto& n : names) total += P(n).size();
+        size_t off = alloc(key, total * 2);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+        for (auto& n : names)
+            for (float v : P(n)) *o++ = f32_to_bf16_host(v);
+    }
+    void geglu(const std::string& t, int C) {  // rows: every 32 = [16 value | 16 gate]
+        const auto& w = P(t + "ff.net.0.proj.weight");
+        const auto& b = P(t + "ff.net.0.proj.bias");
+        const int H = 4 * C;
+        size_t off = alloc(t + "ff.geglu.weight", w.size() * 2);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+        size_t boff = alloc(t + "ff.geglu.bias", b.size() * 4);
+        float* bo = (float*)(u->hblob.data() + boff);
+        for (int r = 0; r < 2 * H; ++r) {
+            const int grp = r / 32, within = r % 32;
+            const int src = within < 16 ? grp * 16 + within : H + grp * 16 + (within - 16);
+            for (int k = 0; k < C; ++k) o[(size_t)r * C + k] = f32_to_bf16_host(w[(size_t)src * C + k]);
+            bo[r] = b[src];
+        }
+    }
+    void resnet(const std::string& p, int cin, int cout) {
+        f32(p + "norm1.weight"); f32(p + "norm1.bias");
+        conv3(p + "conv1.weight", cout, cin); f32(p + "conv1.bias");
+        f32(p + "norm2.weight"); f32(p + "norm2.bias");
+        conv3(p + "conv2.weight", cout, cout); f32(p + "conv2.bias");
+        if (cin != cout) { bf16_same(p + "conv_shortcut.weight"); f32(p + "conv_shortcut.bias"); }
+    }
+    void transformer(const std::string& p, int c) {
+        f32(p + "norm.weight"); f32(p + "norm.bias");
+        bf16_same(p + "proj_in.weight"); f32(p + "proj_in.bias");
+        const std::string t = p + "transformer_blocks.0.";
+        for (int i = 1; i <= 3; ++i) { f32(t + "norm" + std::to_string(i) + ".weight"); f32(t + "norm" + std::to_string(i) + ".bias"); }
+        concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"});
+        bf16_same(t + "attn1.to_out.0.weight"); f32(t + "attn1.to_out.0.bias");
+        bf16_same(t + "attn2.to_q.weight");
+        concat_rows(t + "attn2.kv.weight", {t + "attn2.to_k.weight", t + "attn2.to_v.weight"});
+        bf16_same(t + "attn2.to_out.0.weight"); f32(t + "attn2.to_out.0.bias");
+        geglu(t, c);
+        bf16_same(t + "ff.net.2.weight"); f32(t + "ff.net.2.bias");
+        bf16_same(p + "proj_out.weight"); f32(p + "proj_out.bias");
+    }
+};
+
+// walks the architecture once; F gets (kind, prefix, cin, cout/c) callbacks in forward order
+template <class FR, class FT>
+void walk_blocks(const sd_unet_config& c, FR&& on_resnet, FT&& on_transformer) {
+    const int nl = c.num_levels;
+    int ch = c.block_out_channels[0];
+    std::vector<int> skip_ch{ch};
+    for (int i = 0; i < nl; ++i) {
+        const int co = c.block_out_channels[i];
+        const std::string bp = "down_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            on_resnet(bp + "resnets." + std::to_string(j) + ".", ch, co);
+            ch = co;
+            if (c.attn_levels[i]) on_transformer(bp + "attentions." + std::to_string(j) + ".", co);
+            skip_ch.push_back(co);
+        }
+        if (i < nl - 1) skip_ch.push_back(co);
+    }
+    on_resnet("mid_block.resnets.0.", ch, ch);
+    on_transformer("mid_block.attentions.0.", ch);
+    on_resnet("mid_block.resnets.1.", ch, ch);
+    for (int i = 0; i < nl; ++i) {
+        const int lev = nl - 1 - i, co = c.block_out_channels[lev];
+        const std::string bp = "up_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            const int sc = skip_ch.back();
+            skip_ch.pop_back();
+            on_resnet(bp + "resnets." + std::to_string(j) + ".", ch + sc, co);
+            ch = co;
+            if (c.attn_levels[lev]) on_transformer(bp + "attentions." + std::to_string(j) + ".", co);
+        }
+    }
+}
+
+int pack_all(sd_unet* u) {
+    const sd_unet_config& c = u->cfg;
+    Packer pk{u};
+    const int c0 = c.block_out_channels[0], temb = 4 * c0, nl = c.num_levels;
+    pk.bf16_same("time_embedding.linear_1.weight"); pk.f32("time_embedding.linear_1.bias");
+    pk.bf16_same("time_embedding.linear_2.weight"); pk.f32("time_embedding.linear_2.bias");
+    {   // conv_in: [O][I][3][3] -> Wt[k = ic*9+tap][O] fp32
+        const auto& d = pk.P("conv_in.weight");
+        const int O = c0, I = c.in_channels;
+        size_t off = pk.alloc("conv_in.weight", d.size() * 4);
+        float* o = (float*)(u->hblob.data() + off);
+        for (int oc = 0; oc < O; ++oc)
+            for (int k = 0; k < I * 9; ++k) o[(size_t)k * O + oc] = d[(size_t)oc * I * 9 + k];
+        pk.f32("conv_in.bias");
+    }
+    std::vector<std::string> tw, tb;
+    long toff = 0;
+    walk_blocks(c,
+        [&](const std::string& p, int cin, int cout) {
+            pk.resnet(p, cin, cout);
+            tw.push_back(p + "time_emb_proj.weight");
+            tb.push_back(p + "time_emb_proj.bias");
+            u->tproj_off[p] = toff;
+            toff += cout;
+        },
+        [&](const std::string& p, int cc) { pk.transformer(p, cc); });
+    u->tproj_total = toff;
+    pk.concat_rows("tproj.weight", tw);
+    {
+        size_t off = pk.alloc("tproj.bias", (size_t)toff * 4);
+        float* o = (float*)(u->hblob.data() + off);
+        for (auto& n : tb)
+            for (float v : pk.P(n)) *o++ = v;
+    }
+    (void)temb;
+    for (int i = 0; i < nl - 1; ++i) {
+        const int co = c.block_out_channels[i];
+        const std::string d = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv.";
+        pk.conv3(d + "weight", co, co); pk.f32(d + "bias");
+        const int lev = nl - 1 - i, cu = c.block_out_channels[lev];
+        const std::string up = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
+        pk.conv3(up + "weight", cu, cu); pk.f32(up + "bias");
+    }
+    pk.f32("conv_norm_out.weight"); pk.f32("conv_norm_out.bias");
+    pk.conv3("conv_out.weight", c.out_channels, c0); pk.f32("conv_out.bias");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan builder
+// ---------------------------------------------------------------------------------------------
+struct Builder {
+    sd_unet* u;
+    Plan& pl;
+    int UB;
+    std::vector<Wrap> wrapstack;
+
+    int tensor(size_t bytes, bool persistent = false) {
+        Tn t;
+        t.bytes = (bytes + 255) / 256 * 256;
+        t.persistent = persistent;
+        pl.tensors.push_back(t);
+        return (int)pl.tensors.size() - 1;
+    }
+    size_t W(const std::string& k) {
+        auto it = u->woff.find(k);
+        if (it == u->woff.end()) { fprintf(stderr, "libsdhip: missing packed weight %s\n", k.c_str()); abort(); }
+        return it->second;
+    }
+    Op& push(Op op) {
+        op.nwrap = (int)wrapstack.size();
+        for (int i = 0; i < op.nwrap; ++i) op.wraps[i] = wrapstack[i];
+        pl.ops.push_back(op);
+        return pl.ops.back();
+    }
+    int gn(int x1, int c1, int x2, int c2, int hw, const std::string& g, const std::string& b, float eps, int silu) {
+        Op o; o.kind = OP_GN; o.x1 = x1; o.C1 = c1; o.x2 = x2; o.C2 = c2; o.HW = hw; o.B = UB;
+        o.g = W(g); o.be = W(b); o.eps = eps; o.silu = silu;
+        o.nsplit = sd_groupnorm_nsplit(UB, hw);
+        o.aux = tensor((size_t)UB * o.nsplit * u->cfg.norm_num_groups * 2 * 4);
+        o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
+        push(o);
+        return o.out;
+    }
+    int conv3(int x, int hin, int cin, int cout, int stride, int up, const std::string& w, const std::string& b,
+              long b2idx, int b2t, int r) {
+        Op o; o.kind = OP_CONV3; o.x1 = x; o.B = UB; o.Hin = hin; o.Win = hin; o.Cin = cin; o.N = cout;
+        o.stride = stride; o.up = up;
+        const int hv = hin << up;
+        o.Hout = o.Wout = (hv + 2 - 3) / stride + 1;
+        o.M = UB * o.Hout * o.Wout; o.K = 9 * cin;
+        o.w = W(w); o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
+        o.out = tensor((size_t)o.M * cout * 2);
+        push(o);
+        return o.out;
+    }
+    int gemm(int x1, int k1, int x2, int k2, int M, int N, const std::string& w, const std::string& b, int r, int epi) {
+        Op o; o.kind = OP_GEMM; o.x1 = x1; o.x2 = x2; o.K1 = k1; o.K = k1 + k2; o.M = M; o.N = N; o.epi = epi;
+        o.w = W(w); o.b = b.empty() ? NOFF : W(b); o.r = r;
+        o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
+        push(o);
+        return o.out;
+    }
+    int ln(int x, int M, int C, const std::string& g, const std::string& b) {
+        Op o; o.kind = OP_LN; o.x1 = x; o.M = M; o.N = C; o.g = W(g); o.be = W(b); o.eps = 1e-5f;
+        o.out = tensor((size_t)M * C * 2);
+        push(o);
+        return o.out;
+    }
+    int attn(int q, long qoff, long ldq, int kv, long koff, long voff, long ldkv, int nq, int nk, int C) {
+        Op o; o.kind = OP_ATTN; o.x1 = q; o.x2 = kv; o.qoff = qoff; o.koff = koff; o.voff = voff;
+        o.ldq = ldq; o.ldk = o.ldv = ldkv; o.ldo = C; o.B = UB; o.heads = u->cfg.num_heads; o.D = C / u->cfg.num_heads;
+        o.Nq = nq; o.Nk = nk;
+        o.out = tensor((size_t)UB * nq * C * 2);
+        push(o);
+        return o.out;
+    }
+    // ResnetBlock2D (A.3); input may be a virtual channel concat [x1 | x2]
+    int resnet(const std::string& p, int x1, int c1, int x2, int c2, int cout, int res, int tproj_t) {
+        const int hw = res * res, cin = c1 + c2, M = UB * hw;
+        int t1 = gn(x1, c1, x2, c2, hw, p + "norm1.weight", p + "norm1.bias", u->cfg.norm_eps, 1);
+        int t2 = conv3(t1, res, cin, cout, 1, 0, p + "conv1.weight", p + "conv1.bias", u->tproj_off.at(p), tproj_t, -1);
+        int t3 = gn(t2, cout, -1, 0, hw, p + "norm2.weight", p + "norm2.bias", u->cfg.norm_eps, 1);
+        int sc = x1;
+        if (cin != cout) sc = gemm(x1, c1, x2, c2, M, cout, p + "conv_shortcut.weight", p + "conv_shortcut.bias", -1, 0);
+        return conv3(t3, res, cout, cout, 1, 0, p + "conv2.weight", p + "conv2.bias", 0, -1, sc);
+    }
+    // Transformer2DModel with one BasicTransformerBlock (A.4)
+    int transformer(const std::string& p, int x, int C, int res) {
+        const int hw = res * res, M = UB * hw, L = u->cfg.context_len;
+        const std::string t = p + "transformer_blocks.0.";
+        int g = gn(x, C, -1, 0, hw, p + "norm.weight", p + "norm.bias", 1e-6f, 0);
+        int h0 = gemm(g, C, -1, 0, M, C, p + "proj_in.weight", p + "proj_in.bias", -1, 0);
+        int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias");
+        int qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0);
+        int a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
+        int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
+        int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
+        int q2 = gemm(n2, C, -1, 0, M, C, t + "attn2.to_q.weight", "", -1, 0);
+        // K|V of the prompt: projected once per sampling run by sd_unet_set_context
+        int kv = tensor((size_t)UB * L * 2 * C * 2, /*persistent=*/true);
+        pl.ctx_kv.push_back(kv);
+        pl.ctx_w.push_back(W(t + "attn2.kv.weight"));
+        pl.ctx_c.push_back(C);
+        int a2 = attn(q2, 0, C, kv, 0, C, 2 * C, hw, L, C);
+        int h2 = gemm(a2, C, -1, 0, M, C, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", h1, 0);
+        int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias");
+        int ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1);
+        int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0);
+        return gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
+    }
+
+    void build() {
+        const sd_unet_config& c = u->cfg;
+        const int nl = c.num_levels, c0 = c.block_out_channels[0], temb = 4 * c0;
+        const int L = c.context_len;
+        pl.ctx_bf16 = tensor((size_t)UB * L * c.cross_attention_dim * 2, true);
+        // ---- time embedding (M = 1: the reference passes one scalar t per call) ----
+        int t_sin = tensor((size_t)c0 * 4), t_h1 = tensor((size_t)temb * 4), t_emb = tensor((size_t)temb * 4);
+        int t_proj = tensor((size_t)u->tproj_total * 4);
+        { Op o; o.kind = OP_SINUSOID; o.out = t_sin; o.N = c0; push(o); }
+        { Op o; o.kind = OP_GEMV; o.x1 = t_sin; o.out = t_h1; o.N = temb; o.K = c0; o.w = W("time_embedding.linear_1.weight"); o.b = W("time_embedding.linear_1.bias"); push(o); }
+        { Op o; o.kind = OP_GEMV; o.x1 = t_h1; o.out = t_emb; o.N = temb; o.K = temb; o.silu_in = 1; o.w = W("time_embedding.linear_2.weight"); o.b = W("time_embedding.linear_2.bias"); push(o); }
+        { Op o; o.kind = OP_GEMV; o.x1 = t_emb; o.out = t_proj; o.N = (int)u->tproj_total; o.K = temb; o.silu_in = 1; o.w = W("tproj.weight"); o.b = W("tproj.bias"); push(o); }
+        // ---- conv_in ----
+        int res = c.sample_size;
+        int h;
+        { Op o; o.kind = OP_CONV_IN; o.x1 = T_LATENTS; o.B = UB; o.Hin = res; o.Win = res; o.Cin = c.in_channels; o.N = c0;
+          o.w = W("conv_in.weight"); o.b = W("conv_in.bias"); o.out = tensor((size_t)UB * res * res * c0 * 2); push(o); h = o.out; }
+        pl.taps["conv_in"] = h;
+        int ch = c0;
+        std::vector<int> skips{h}, skip_ch{c0};
+        // ---- down ----
+        for (int i = 0; i < nl; ++i) {
+            const int co = c.block_out_channels[i];
+            const std::string bp = "down_blocks." + std::to_string(i) + ".";
+            wrapstack.push_back(Wrap{0, i, 0});
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                wrapstack.push_back(Wrap{0, i, j});
+                h = resnet(bp + "resnets." + std::to_string(j) + ".", h, ch, -1, 0, co, res, t_proj);
+                ch = co;
+                if (c.attn_levels[i]) h = transformer(bp + "attentions." + std::to_string(j) + ".", h, co, res);
+                wrapstack.pop_back();
+                skips.push_back(h); skip_ch.push_back(co);
+            }
+            if (i < nl - 1) {
+                wrapstack.push_back(Wrap{0, i, c.layers_per_block});
+                const std::string d = bp + "downsamplers.0.conv.";
+                h = conv3(h, res, co, co, 2, 0, d + "weight", d + "bias", 0, -1, -1);
+                wrapstack.pop_back();
+                res /= 2;
+                skips.push_back(h); skip_ch.push_back(co);
+            }
+            wrapstack.pop_back();
+            pl.taps["down" + std::to_string(i)] = h;
+        }
+        // ---- mid ----
+        wrapstack.push_back(Wrap{1, 0, 0});
+        h = resnet("mid_block.resnets.0.", h, ch, -1, 0, ch, res, t_proj);
+        h = transformer("mid_block.attentions.0.", h, ch, res);
+        h = resnet("mid_block.resnets.1.", h, ch, -1, 0, ch, res, t_proj);
+        wrapstack.pop_back();
+        pl.taps["mid"] = h;
+        // ---- up ----
+        const int nres = c.layers_per_block + 1;
+        for (int i = 0; i < nl; ++i) {
+            const int lev = nl - 1 - i, co = c.block_out_channels[lev], rb = nl - 1 - i;
+            const std::string bp = "up_blocks." + std::to_string(i) + ".";
+            wrapstack.push_back(Wrap{2, rb, 0});
+            for (int j = 0; j < nres; ++j) {
+                const int s = skips.back(), sc = skip_ch.back();
+                skips.pop_back(); skip_ch.pop_back();
+                const int rl = nres - 1 - j;
+                wrapstack.push_back(Wrap{2, rb, rl});
+                h = resnet(bp + "resnets." + std::to_string(j) + ".", h, ch, s, sc, co, res, t_proj);
+                ch = co;
+                if (c.attn_levels[lev]) h = transformer(bp + "attentions." + std::to_string(j) + ".", h, co, res);
+                wrapstack.pop_back();
+            }
+            if (i < nl - 1) {
+                wrapstack.push_back(Wrap{2, rb, 0});
+                const std::string up = bp + "upsamplers.0.conv.";
+                h = conv3(h, res, co, co, 1, 1, up + "weight", up + "bias", 0, -1, -1);
+                wrapstack.pop_back();
+                res *= 2;
+            }
+            wrapstack.pop_back();
+            pl.taps["up" + std::to_string(i)] = h;
+        }
+        // ---- out ----
+        int g = gn(h, ch, -1, 0, res * res, "conv_norm_out.weight", "conv_norm_out.bias", c.norm_eps, 1);
+        { Op o; o.kind = OP_CONV_OUT; o.x1 = g; o.out = T_EPS; o.B = UB; o.Hin = res; o.Win = res; o.Cin = ch; o.N = c.out_channels;
+          o.w = W("conv_out.weight"); o.b = W("conv_out.bias"); push(o); }
+    }
+};
+
+bool wrap_skipped(const Wrap& w, int branch) {
+    const int cache_layer_id = branch % 3, cache_block_id = branch / 3;
+    if (w.block_i > cache_block_id || w.type == 1) return true;
+    if (w.block_i < cache_block_id) return false;
+    return w.type == 0 ? w.layer_i >= cache_layer_id : w.layer_i > cache_layer_id;
+}
+
+void op_tensors(const Op& o, int ins[5], int& nin) {
+    nin = 0;
+    for (int t : {o.x1, o.x2, o.r, o.b2t})
+        if (t >= 0) ins[nin++] = t;
+}
+
+void assign_memory(sd_unet* u, Plan& pl) {
+    const int nops = (int)pl.ops.size();
+    // DeepCache: which ops are skipped on skip steps, and which tensors they leave behind for running ops
+    pl.skipped.assign(nops, 0);
+    if (pl.branch >= 0) {
+        for (int i = 0; i < nops; ++i)
+            for (int k = 0; k < pl.ops[i].nwrap; ++k)
+                if (wrap_skipped(pl.ops[i].wraps[k], pl.branch)) pl.skipped[i] = 1;
+        std::vector<int> producer(pl.tensors.size(), -1);
+        for (int i = 0; i < nops; ++i)
+            if (pl.ops[i].out >= 0) producer[pl.ops[i].out] = i;
+        for (int i = 0; i < nops; ++i) {
+            if (pl.skipped[i]) continue;
+            int ins[5], nin;
+            op_tensors(pl.ops[i], ins, nin);
+            for (int k = 0; k < nin; ++k) {
+                const int p = producer[ins[k]];
+                if (p >= 0 && pl.skipped[p]) pl.tensors[ins[k]].persistent = true;
+            }
+        }
+    }
+    if (u->debug_taps)
+        for (auto& kv : pl.taps) pl.tensors[kv.second].persistent = true;
+    // lifetimes over the full plan
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = pl.ops[i];
+        int ins[5], nin;
+        op_tensors(o, ins, nin);
+        for (int k = 0; k < nin; ++k) pl.tensors[ins[k]].last = std::max(pl.tensors[ins[k]].last, i);
+        for (int t : {o.out, o.aux})
+            if (t >= 0) {
+                if (pl.tensors[t].def < 0) pl.tensors[t].def = i;
+                pl.tensors[t].last = std::max(pl.tensors[t].last, i);
+            }
+    }
+    // persistent region
+    size_t off = 0;
+    for (auto& t : pl.tensors)
+        if (t.persistent) { t.off = off; off += t.bytes; }
+    const size_t arena0 = off;
+    // arena: first-fit over live intervals
+    struct Live { size_t off, bytes; int last; };
+    std::vector<Live> live;
+    size_t high = arena0;
+    std::vector<std::vector<int>> def_at(nops);
+    for (int t = 0; t < (int)pl.tensors.size(); ++t)
+        if (!pl.tensors[t].persistent && pl.tensors[t].def >= 0) def_at[pl.tensors[t].def].push_back(t);
+    for (int i = 0; i < nops; ++i) {
+        for (int t : def_at[i]) {
+            std::sort(live.begin(), live.end(), [](const Live& a, const Live& b) { return a.off < b.off; });
+            size_t cur = arena0;
+            for (const Live& l : live) {
+                if (l.off >= cur + pl.tensors[t].bytes) break;
+                cur = std::max(cur, l.off + l.bytes);
+            }
+            pl.tensors[t].off = cur;
+            live.push_back(Live{cur, pl.tensors[t].bytes, pl.tensors[t].last});
+            high = std::max(high, cur + pl.tensors[t].bytes);
+        }
+        live.erase(std::remove_if(live.begin(), live.end(), [i](const Live& l) { return l.last <= i; }), live.end());
+    }
+    pl.total_bytes = high + 4096;
+}
+
+int get_plan(sd_unet* u, int UB, int branch, Plan** out) {
+    SD_REQUIRE(u && u->finalized, "unet: parameters not finalized");
+    SD_REQUIRE(UB > 0 && UB <= 4096, "unet: bad batch %d", UB);
+    SD_REQUIRE(branch < 3 * u->cfg.num_levels, "unet: cache_branch_id %d out of range", branch);
+    if (branch < 0) branch = -1;
+    auto key = std::make_pair(UB, branch);
+    auto it = u->plans.find(key);
+    if (it == u->plans.end()) {
+        Plan pl;
+        pl.UB = UB;
+        pl.branch = branch;
+        Builder b{u, pl, UB, {}};
+        b.build();
+        assign_memory(u, pl);
+        it = u->plans.emplace(key, std::move(pl)).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* latents, int latent_batch, float* eps_out,
+           float timestep, hipStream_t stream) {
+    auto T = [&](int id) -> char* { return id >= 0 ? ws + pl.tensors[id].off : nullptr; };
+    const char* wb = u->dweights;
+    switch (o.kind) {
+        case OP_SINUSOID:
+            return sd_launch_timestep_sinusoid(timestep, (float*)T(o.out), o.N, stream);
+        case OP_GEMV:
+            return sd_launch_gemv((const float*)T(o.x1), (const bf16_t*)(wb + o.w), (const float*)(wb + o.b),
+                                  (float*)T(o.out), o.N, o.K, o.silu_in, stream);
+        case OP_CONV_IN:
+            return sd_launch_conv_in(latents, latent_batch, (const float*)(wb + o.w), (const float*)(wb + o.b),
+                                     (bf16_t*)T(o.out), o.B, o.Hin, o.Win, o.Cin, o.N, stream);
+        case OP_GN: {
+            GroupNormArgs a;
+            a.x1 = (const bf16_t*)T(o.x1); a.C1 = o.C1; a.x2 = (const bf16_t*)T(o.x2); a.C2 = o.C2;
+            a.gamma = (const float*)(wb + o.g); a.beta = (const float*)(wb + o.be);
+            a.y = (bf16_t*)T(o.out); a.partial = (float*)T(o.aux);
+            a.B = o.B; a.HW = o.HW; a.groups = u->cfg.norm_num_groups; a.nsplit = o.nsplit; a.eps = o.eps; a.silu = o.silu;
+            return sd_launch_groupnorm(a, stream);
+        }
+        case OP_CONV3: {
+            GemmArgs a;
+            a.X = (const bf16_t*)T(o.x1); a.W = (const bf16_t*)(wb + o.w); a.bias = (const float*)(wb + o.b);
+            a.bias2 = o.b2t >= 0 ? (const float*)T(o.b2t) + o.b2idx : nullptr;
+            a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out); a.ldc = o.N;
+            a.M = o.M; a.N = o.N; a.K = o.K; a.K1 = o.K;
+            a.Hin = o.Hin; a.Win = o.Win; a.Cin = o.Cin; a.Hout = o.Hout; a.Wout = o.Wout; a.stride = o.stride; a.up = o.up;
+            a.zero_page = g_zero_page;
+            return sd_launch_conv3x3(a, stream);
+        }
+        case OP_GEMM: {
+            GemmArgs a;
+            a.X = (const bf16_t*)T(o.x1); a.ldx = o.K1; a.X2 = (const bf16_t*)T(o.x2); a.ldx2 = o.K - o.K1; a.K1 = o.K1;
+            a.W = (const bf16_t*)(wb + o.w); a.bias = o.b != NOFF ? (const float*)(wb + o.b) : nullptr;
+            a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out); a.ldc = o.epi ? o.N / 2 : o.N;
+            a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page;
+            return sd_launch_gemm(a, o.epi, stream);
+        }
+        case OP_LN:
+            return sd_launch_layernorm((const bf16_t*)T(o.x1), (const float*)(wb + o.g), (const float*)(wb + o.be),
+                                       (bf16_t*)T(o.out), o.M, o.N, o.eps, stream);
+        case OP_ATTN: {
+            AttnArgs a;
+            a.Q = (const bf16_t*)T(o.x1) + o.qoff; a.ldq = o.ldq;
+            a.K = (const bf16_t*)T(o.x2) + o.koff; a.ldk = o.ldk;
+            a.V = (const bf16_t*)T(o.x2) + o.voff; a.ldv = o.ldv;
+            a.O = (bf16_t*)T(o.out); a.ldo = o.ldo;
+            a.B = o.B; a.heads = o.heads; a.Nq = o.Nq; a.Nk = o.Nk; a.D = o.D;
+            a.scale = 1.0f / sqrtf((float)o.D);
+            return sd_launch_attention(a, stream);
+        }
+        case OP_CONV_OUT:
+            return sd_launch_conv_out((const bf16_t*)T(o.x1), (const bf16_t*)(wb + o.w), (const float*)(wb + o.b), eps_out,
+                                      o.B, o.Hin, o.Win, o.Cin, o.N, stream);
+    }
+    sd_set_error("unet: unknown op kind %d", o.kind);
+    return -1;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int sd_unet_create(const sd_unet_config* cfg, sd_unet** out) {
+    SD_REQUIRE(cfg && out, "sd_unet_create: null argument");
+    SD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8, "sd_unet_create: num_levels %d", cfg->num_levels);
+    SD_REQUIRE(cfg->in_channels == 4 && cfg->out_channels >= 1 && cfg->out_channels <= 4, "sd_unet_create: in/out channels");
+    for (int i = 0; i < cfg->num_levels; ++i) {
+        const int c = cfg->block_out_channels[i];
+        SD_REQUIRE(c % 64 == 0 && c % cfg->norm_num_groups == 0 && c / cfg->norm_num_groups >= 8,
+                   "sd_unet_create: block_out_channels[%d]=%d must be a multiple of 64 with >= 8 channels per group", i, c);
+        if (cfg->attn_levels[i]) {
+            const int d = c / cfg->num_heads;
+            SD_REQUIRE(c % cfg->num_heads == 0 && (d == 40 || d == 80 || d == 160),
+                       "sd_unet_create: head dim %d at level %d not built (40/80/160)", d, i);
+        }
+    }
+    const int dmid = cfg->block_out_channels[cfg->num_levels - 1] / cfg->num_heads;
+    SD_REQUIRE(dmid == 40 || dmid == 80 || dmid == 160, "sd_unet_create: mid-block head dim %d not built", dmid);
+    SD_REQUIRE(cfg->cross_attention_dim % 64 == 0, "sd_unet_create: cross_attention_dim must be a multiple of 64");
+    SD_REQUIRE(cfg->sample_size % (1 << (cfg->num_levels - 1)) == 0, "sd_unet_create: sample_size not divisible");
+    SD_REQUIRE(cfg->context_len >= 1, "sd_unet_create: context_len");
+    if (ensure_zero_page()) return -2;
+    sd_unet* u = new sd_unet();
+    u->cfg = *cfg;
+    u->debug_taps = getenv("SD_DEBUG_TAPS") != nullptr;
+    enumerate_params(u);
+    *out = u;
+    return 0;
+}
+
+extern "C" void sd_unet_destroy(sd_unet* u) {
+    if (!u) return;
+    if (u->dweights) (void)hipFree(u->dweights);
+    delete u;
+}
+
+extern "C" int sd_unet_num_params(const sd_unet* u) { return u ? (int)u->params.size() : -1; }
+
+extern "C" int sd_unet_param_info(const sd_unet* u, int index, char* name, int name_cap, long long shape[4], int* ndim) {
+    SD_REQUIRE(u && index >= 0 && index < (int)u->params.size(), "param_info: bad index %d", index);
+    const ParamSpec& p = u->params[index];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", p.name.c_str());
+    for (int i = 0; i < 4; ++i) shape[i] = i < (int)p.shape.size() ? p.shape[i] : 1;
+    if (ndim) *ndim = (int)p.shape.size();
+    return 0;
+}
+
+extern "C" int sd_unet_load_param(sd_unet* u, const char* name, const float* host_data, long long numel) {
+    SD_REQUIRE(u && name && host_data, "load_param: null argument");
+    SD_REQUIRE(!u->finalized, "load_param: handle already finalized");
+    auto it = u->pindex.find(name);
+    SD_REQUIRE(it != u->pindex.end(), "load_param: unknown parameter '%s'", name);
+    ParamSpec& p = u->params[it->second];
+    SD_REQUIRE(p.numel() == numel, "load_param: '%s' expects %lld elements, got %lld", name, p.numel(), numel);
+    p.data.assign(host_data, host_data + numel);
+    p.loaded = true;
+    return 0;
+}
+
+extern "C" int sd_unet_finalize(sd_unet* u) {
+    SD_REQUIRE(u, "finalize: null handle");
+    SD_REQUIRE(!u->finalized, "finalize: already finalized");
+    for (auto& p : u->params) SD_REQUIRE(p.loaded, "finalize: parameter '%s' was never loaded", p.name.c_str());
+    if (pack_all(u)) return -1;
+    SD_CHECK_HIP(hipMalloc((void**)&u->dweights, u->hblob.size()));
+    SD_CHECK_HIP(hipMemcpy(u->dweights, u->hblob.data(), u->hblob.size(), hipMemcpyHostToDevice));
+    std::vector<unsigned char>().swap(u->hblob);
+    for (auto& p : u->params) std::vector<float>().swap(p.data);
+    u->finalized = true;
+    return 0;
+}
+
+extern "C" long long sd_unet_workspace_bytes(sd_unet* u, int unet_batch, int cache_branch_id) {
+    Plan* pl;
+    if (get_plan(u, unet_batch, cache_branch_id, &pl)) return -1;
+    return (long long)pl->total_bytes;
+}
+
+extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, int unet_batch, int cache_branch_id,
+                                   void* workspace, long long workspace_bytes) {
+    SD_REQUIRE(ehs && workspace, "set_context: null argument");
+    Plan* plp;
+    int rc = get_plan(u, unet_batch, cache_branch_id, &plp);
+    if (rc) return rc;
+    Plan& pl = *plp;
+    SD_REQUIRE((long long)pl.total_bytes <= workspace_bytes, "set_context: workspace too small (%lld < %zu)",
+               workspace_bytes, pl.total_bytes);
+    SD_REQUIRE(((uintptr_t)workspace & 255) == 0, "set_context: workspace must be 256-byte aligned");
+    char* ws = (char*)workspace;
+    const int L = u->cfg.context_len, CD = u->cfg.cross_attention_dim, M = unet_batch * L;
+    bf16_t* cb = (bf16_t*)(ws + pl.tensors[pl.ctx_bf16].off);
+    if ((rc = sd_launch_f32_to_bf16(ehs, cb, (long)M * CD, (hipStream_t)stream))) return rc;
+    for (size_t i = 0; i < pl.ctx_kv.size(); ++i) {
+        GemmArgs a;
+        a.X = cb; a.ldx = CD; a.K1 = CD; a.K = CD; a.M = M; a.N = 2 * pl.ctx_c[i];
+        a.W = (const bf16_t*)(u->dweights + pl.ctx_w[i]);
+        a.C = (bf16_t*)(ws + pl.tensors[pl.ctx_kv[i]].off); a.ldc = a.N;
+        a.zero_page = g_zero_page;
+        if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int sd_unet_forward(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                               float timestep, float* eps_out, void* workspace, long long workspace_bytes,
+                               int cache_mode, int cache_branch_id) {
+    SD_REQUIRE(latents && eps_out && workspace, "forward: null argument");
+    SD_REQUIRE(latent_batch > 0 && unet_batch % latent_batch == 0, "forward: unet batch %d not a multiple of latent batch %d",
+               unet_batch, latent_batch);
+    SD_REQUIRE(cache_mode >= 0 && cache_mode <= 2, "forward: cache_mode %d", cache_mode);
+    SD_REQUIRE(cache_mode == SD_CACHE_OFF || cache_branch_id >= 0, "forward: DeepCache modes need cache_branch_id >= 0");
+    Plan* pl;
+    int rc = get_plan(u, unet_batch, cache_branch_id, &pl);
+    if (rc) return rc;
+    SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "forward: workspace too small (%lld < %zu)", workspace_bytes,
+               pl->total_bytes);
+    SD_REQUIRE(((uintptr_t)workspace & 255) == 0, "forward: workspace must be 256-byte aligned");
+    for (size_t i = 0; i < pl->ops.size(); ++i) {
+        if (cache_mode == SD_CACHE_SKIP && pl->skipped[i]) continue;
+        if ((rc = run_op(u, *pl, pl->ops[i], (char*)workspace, latents, latent_batch, eps_out, timestep, (hipStream_t)stream)))
+            return rc;
+    }
+    return 0;
+}
+
+extern "C" int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host_out, long long numel,
+                                    void* workspace, int unet_batch, int cache_branch_id) {
+    SD_REQUIRE(u && u->debug_taps, "debug_tensor: create the handle with SD_DEBUG_TAPS=1 in the environment");
+    Plan* pl;
+    int rc = get_plan(u, unet_batch, cache_branch_id, &pl);
+    if (rc) return rc;
+    auto it = pl->taps.find(name);
+    SD_REQUIRE(it != pl->taps.end(), "debug_tensor: unknown tap '%s'", name);
+    const Tn& t = pl->tensors[it->second];
+    SD_REQUIRE((size_t)numel * 2 <= t.bytes, "debug_tensor: '%s' holds at most %zu elements", name, t.bytes / 2);
+    std::vector<unsigned short> tmp(numel);
+    SD_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    SD_CHECK_HIP(hipMemcpy(tmp.data(), (char*)workspace + t.off, (size_t)numel * 2, hipMemcpyDeviceToHost));
+    for (long long i = 0; i < numel; ++i) {
+        unsigned v = (unsigned)tmp[i] << 16;
+        memcpy(&host_out[i], &v, 4);
+    }
+    return 0;
+}
+
+extern "C" int sd_sched_step(void* stream, const float* eps, int cfg, float guidance, const float* x, const float* m1,
+                             const float* m2, const float* noise, float* prev, float* y2, float* m_out,
+                             const float coef[9], long long n) {
+    SD_REQUIRE(coef, "sched_step: null coefficients");
+    StepCoef c{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
+    return sd_launch_sched_step(eps, cfg, guidance, x, m1, m2, noise, prev, y2, m_out, c, (long)n, (hipStream_t)stream);
+}
+
+// ---- operator-level entry points -------------------------------------------------------------
+extern "C" int sd_op_gemm(void* stream, const void* X, long long ldx, const void* X2, long long ldx2, int K1,
+                          const void* W, const float* bias, const float* bias2, const void* R, long long ldr, void* C,
+                          long long ldc, int M, int N, int K, int epi) {
+    if (ensure_zero_page()) return -2;
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.X2 = (const bf16_t*)X2; a.ldx2 = ldx2; a.K1 = K1;
+    a.W = (const bf16_t*)W; a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = ldr;
+    a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
+    return sd_launch_gemm(a, epi, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2,
+                             const void* R, void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = Cout;
+    a.C = (bf16_t*)Y; a.ldc = Cout;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = stride; a.up = upsample ? 1 : 0;
+    a.Hout = ((Hin << a.up) + 2 - 3) / stride + 1; a.Wout = ((Win << a.up) + 2 - 3) / stride + 1;
+    a.M = B * a.Hout * a.Wout; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page;
+    return sd_launch_conv3x3(a, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                               const float* beta, void* y, int B, int HW, int groups, float eps, int silu) {
+    GroupNormArgs a;
+    a.x1 = (const bf16_t*)x1; a.C1 = C1; a.x2 = (const bf16_t*)x2; a.C2 = C2; a.gamma = gamma; a.beta = beta;
+    a.y = (bf16_t*)y; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
+    a.nsplit = sd_groupnorm_nsplit(B, HW);
+    float* partial = nullptr;
+    SD_CHECK_HIP(hipMalloc((void**)&partial, (size_t)B * a.nsplit * groups * 2 * sizeof(float)));
+    a.partial = partial;
+    int rc = sd_launch_groupnorm(a, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(partial);
+    return rc;
+}
+
+extern "C" int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows,
+                               int C, float eps) {
+    return sd_launch_layernorm((const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_attention(void* stream, const void* Q, long long ldq, const void* K, long long ldk, const void* V,
+                               long long ldv, void* O, long long ldo, int B, int heads, int Nq, int Nk, int D, float scale) {
+    AttnArgs a;
+    a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+    a.O = (bf16_t*)O; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
+    return sd_launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_conv_in(void* stream, const float* x, int Bsrc, const float* Wt, const float* bias, void* y, int B,
+                             int H, int W, int Cin, int Cout) {
+    return sd_launch_conv_in(x, Bsrc, Wt, bias, (bf16_t*)y, B, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_conv_out(void* stream, const void* x, const void* Wp, const float* bias, float* y, int B, int H,
+                              int W, int Cin, int Cout) {
+    return sd_launch_conv_out((const bf16_t*)x, (const bf16_t*)Wp, bias, y, B, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_time_embedding(void* stream, float t, const void* W1, const float* b1, const void* W2,
+                                    const float* b2, float* scratch, float* temb, int dim_in, int dim) {
+    int rc;
+    if ((rc = sd_launch_timestep_sinusoid(t, scratch, dim_in, (hipStream_t)stream))) return rc;
+    if ((rc = sd_launch_gemv(scratch, (const bf16_t*)W1, b1, scratch + dim_in, dim, dim_in, 0, (hipStream_t)stream))) return rc;
+    return sd_launch_gemv(scratch + dim_in, (const bf16_t*)W2, b2, temb, dim, dim, 1, (hipStream_t)stream);
+}

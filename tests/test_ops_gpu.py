@@ -1,0 +1,272 @@
+"""GPU parity of every hot kernel, called through the C ABI (sd_op_*), against the stock
+PyTorch fp32 CPU operator the reference's CPU path would dispatch to.  Inputs are rounded to
+bf16 first so the comparison isolates kernel arithmetic (fp32 accumulate, bf16 output rounding:
+tolerance rel-L2 <= 6e-3, i.e. ~1.5 bf16 ulp RMS)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from sonicdiffusionbayeslab_amd import _lib
+
+TOL = 6e-3
+
+
+def dev(t, dtype=None):
+    return t.to("cuda", dtype=dtype) if dtype else t.to("cuda")
+
+
+def r16(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_KEEP = []
+
+
+def P(t, dtype=None):
+    """Upload (if needed) and return the device pointer, keeping the tensor alive."""
+    if t is None:
+        return None
+    if t.device.type != "cuda" or (dtype is not None and t.dtype != dtype):
+        t = dev(t, dtype)
+    _KEEP.append(t)
+    return t.data_ptr()
+
+
+@pytest.fixture(autouse=True)
+def _drop_keep():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+@pytest.mark.parametrize("M,N,K,K1,bias,bias2,res", [
+    (256, 320, 320, 320, True, False, False),
+    (300, 320, 640, 640, True, True, True),
+    (130, 640, 960, 640, True, False, True),      # two K segments (virtual concat) + M/N tails
+    (64, 1280, 2560, 1280, False, False, False),
+    (1000, 960, 320, 320, False, False, False),   # fused QKV shape
+])
+def test_gemm(sdlib, M, N, K, K1, bias, bias2, res):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = r16(torch.randn(M, K, generator=g))
+    w = r16(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) if bias else None
+    b2 = torch.randn(N, generator=g) if bias2 else None
+    r = r16(torch.randn(M, N, generator=g)) if res else None
+    ref = x @ w.t()
+    if bias: ref = ref + b
+    if bias2: ref = ref + b2
+    if res: ref = ref + r
+    x1 = dev(x[:, :K1].contiguous(), torch.bfloat16)
+    x2 = dev(x[:, K1:].contiguous(), torch.bfloat16) if K1 < K else None
+    wd = dev(w, torch.bfloat16)
+    bd = dev(b) if bias else None
+    b2d = dev(b2) if bias2 else None
+    rd = dev(r, torch.bfloat16) if res else None
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_gemm(stream(), P(x1), K1, P(x2), K - K1, K1, P(wd), P(bd),
+                                P(b2d), P(rd), N, P(out), N, M, N, K, 0))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL
+
+
+def test_gemm_geglu(sdlib):
+    M, C = 200, 320
+    g = torch.Generator().manual_seed(3)
+    x = r16(torch.randn(M, C, generator=g))
+    w = r16(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    b = torch.randn(8 * C, generator=g)
+    proj = x @ w.t() + b
+    a, gate = proj.chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    H = 4 * C
+    idx = []
+    for r in range(2 * H):
+        grp, within = divmod(r, 32)
+        idx.append(grp * 16 + within if within < 16 else H + grp * 16 + within - 16)
+    idx = torch.tensor(idx)
+    wp, bp = dev(w[idx].contiguous(), torch.bfloat16), dev(b[idx].contiguous())
+    xd = dev(x, torch.bfloat16)
+    out = torch.full((M, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_gemm(stream(), P(xd), C, None, 0, C, P(wp), P(bp), None, None, 0,
+                                P(out), H, M, 8 * C, C, 1))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,up,extras", [
+    (2, 16, 320, 320, 1, 0, True),
+    (1, 16, 640, 320, 1, 0, False),
+    (2, 16, 320, 320, 2, 0, False),
+    (2, 8, 320, 640, 1, 1, False),
+    (3, 6, 64, 64, 1, 0, True),      # M tail (108 rows), single K tile per tap
+])
+def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
+    g = torch.Generator().manual_seed(B * 100 + H + Cin)
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    Ho = ref.shape[-1]
+    b2 = r = None
+    if extras:
+        b2 = torch.randn(Cout, generator=g)
+        r = r16(torch.randn(B, Cout, Ho, Ho, generator=g))
+        ref = ref + b2[None, :, None, None] + r
+    xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    wd = dev(w.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    rd = dev(r.permute(0, 2, 3, 1).contiguous(), torch.bfloat16) if extras else None
+    out = torch.full((B, Ho, Ho, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_conv3x3(stream(), P(xd), P(wd), P(b),
+                                   P(b2) if extras else None, P(rd), P(out), B, H, H, Cin,
+                                   Cout, stride, up))
+    torch.cuda.synchronize()
+    assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [
+    (2, 256, 320, 0, 1, 1e-5),
+    (2, 64, 640, 320, 1, 1e-5),     # concat 960: groups of 30 straddle the tensor boundary
+    (1, 1024, 1280, 1280, 0, 1e-6),
+    (3, 16, 1280, 640, 1, 1e-5),
+])
+def test_groupnorm(sdlib, B, HW, C1, C2, silu, eps):
+    g = torch.Generator().manual_seed(HW + C1)
+    C = C1 + C2
+    x = r16(torch.randn(B, HW, C, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu: ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1)
+    x1 = dev(x[..., :C1].contiguous(), torch.bfloat16)
+    x2 = dev(x[..., C1:].contiguous(), torch.bfloat16) if C2 else None
+    out = torch.full((B, HW, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_groupnorm(stream(), P(x1), C1, P(x2), C2, P(gamma),
+                                     P(beta), P(out), B, HW, 32, eps, silu))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL
+
+
+@pytest.mark.parametrize("rows,C", [(300, 320), (77, 640), (1024, 1280)])
+def test_layernorm(sdlib, rows, C):
+    g = torch.Generator().manual_seed(rows)
+    x = r16(torch.randn(rows, C, generator=g) * 3 + 1)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    out = torch.full((rows, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_layernorm(stream(), P(x, torch.bfloat16), P(gamma),
+                                     P(beta), P(out), rows, C, 1e-5))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,D,spike", [
+    (2, 8, 256, 256, 40, False),
+    (1, 8, 300, 300, 40, True),     # ragged tiles + a spiked key that forces the online-max rescale
+    (2, 8, 256, 77, 40, False),     # prompt cross-attention
+    (1, 8, 128, 128, 80, False),
+    (2, 8, 64, 77, 80, False),
+    (1, 8, 64, 64, 160, True),
+    (2, 8, 16, 77, 160, False),
+    (1, 8, 4096, 4096, 40, False),  # the SD-1.5 64x64 self-attention shape
+])
+def test_attention(sdlib, B, heads, Nq, Nk, D, spike):
+    g = torch.Generator().manual_seed(Nq + D)
+    C = heads * D
+    q = r16(torch.randn(B, Nq, C, generator=g))
+    k = r16(torch.randn(B, Nk, C, generator=g))
+    v = r16(torch.randn(B, Nk, C, generator=g))
+    if spike:  # one late key dominates -> running max jumps in the last tile
+        k[:, Nk - 3] = k[:, Nk - 3] * 6
+    qh = q.view(B, Nq, heads, D).transpose(1, 2)
+    kh = k.view(B, Nk, heads, D).transpose(1, 2)
+    vh = v.view(B, Nk, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, C)
+    # pack K|V side by side like the fused projections do
+    kv = dev(torch.cat([k, v], dim=-1).contiguous(), torch.bfloat16)
+    qd = dev(q, torch.bfloat16)
+    out = torch.full((B, Nq, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    kvp = P(kv)
+    _lib.check(sdlib.sd_op_attention(stream(), P(qd), C, kvp, 2 * C, kvp + 2 * C, 2 * C, P(out), C, B,
+                                     heads, Nq, Nk, D, 1.0 / math.sqrt(D)))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 1e-2   # P is rounded to bf16 before PV
+
+
+def test_conv_in_out(sdlib):
+    g = torch.Generator().manual_seed(11)
+    Bs, B, H, C = 2, 4, 16, 320
+    x = torch.randn(Bs, 4, H, H, generator=g)
+    w = torch.randn(C, 4, 3, 3, generator=g) / 6
+    b = torch.randn(C, generator=g)
+    ref = F.conv2d(torch.cat([x, x]), w, b, padding=1)
+    wt = dev(w.reshape(C, 36).t().contiguous())
+    out = torch.full((B, H, H, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_conv_in(stream(), P(x), Bs, P(wt), P(b), P(out), B, H, H, 4, C))
+    torch.cuda.synchronize()
+    assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
+    # conv_out
+    y = r16(torch.randn(B, C, H, H, generator=g))
+    w2 = r16(torch.randn(4, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b2 = torch.randn(4, generator=g)
+    ref2 = F.conv2d(y, w2, b2, padding=1)
+    yd = dev(y.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    wp = dev(w2.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    out2 = torch.full((B, 4, H, H), float("nan"), device="cuda")
+    _lib.check(sdlib.sd_op_conv_out(stream(), P(yd), P(wp), P(b2), P(out2), B, H, H, C, 4))
+    torch.cuda.synchronize()
+    assert rel_l2(out2, ref2) < 1e-5
+
+
+def test_time_embedding(sdlib):
+    g = torch.Generator().manual_seed(5)
+    w1 = r16(torch.randn(1280, 320, generator=g) / 18); b1 = torch.randn(1280, generator=g)
+    w2 = r16(torch.randn(1280, 1280, generator=g) / 36); b2 = torch.randn(1280, generator=g)
+    for t in (981.0, 501.0, 1.0):
+        half = 160
+        f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        emb = torch.cat([torch.cos(t * f), torch.sin(t * f)])
+        ref = F.linear(F.silu(F.linear(emb, w1, b1)), w2, b2)
+        scratch = torch.zeros(320 + 1280, device="cuda")
+        out = torch.zeros(1280, device="cuda")
+        _lib.check(sdlib.sd_op_time_embedding(stream(), t, P(w1, torch.bfloat16), P(b1),
+                                              P(w2, torch.bfloat16), P(b2), P(scratch),
+                                              P(out), 320, 1280))
+        torch.cuda.synchronize()
+        assert rel_l2(out, ref) < 1e-4
+
+
+def test_sched_step_kernel(sdlib):
+    import ctypes
+    g = torch.Generator().manual_seed(9)
+    n = 2 * 4 * 16 * 16
+    eps = torch.randn(2 * n, generator=g); x = torch.randn(n, generator=g)
+    m1 = torch.randn(n, generator=g); m2 = torch.randn(n, generator=g); z = torch.randn(n, generator=g)
+    coef = [0.9, -0.3, 0.2, -0.1, 0.05, 1.3, -0.7, 0.4, 0.6]
+    gs = 7.5
+    e = eps[:n] + gs * (eps[n:] - eps[:n])
+    prev = coef[0] * x + coef[1] * e + coef[2] * m1 + coef[3] * m2 + coef[4] * z
+    y2 = coef[5] * x + coef[6] * e
+    mo = coef[7] * x + coef[8] * e
+    d = [dev(t) for t in (eps, x, m1, m2, z)]
+    o = [torch.zeros(n, device="cuda") for _ in range(3)]
+    carr = (ctypes.c_float * 9)(*coef)
+    _lib.check(sdlib.sd_sched_step(stream(), P(d[0]), 1, gs, P(d[1]), P(d[2]), P(d[3]),
+                                   P(d[4]), P(o[0]), P(o[1]), P(o[2]), carr, n))
+    torch.cuda.synchronize()
+    for got, ref in zip(o, (prev, y2, mo)):
+        assert torch.allclose(got.cpu(), ref, rtol=1e-5, atol=1e-5)
