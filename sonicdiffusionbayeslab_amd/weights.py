@@ -1,0 +1,138 @@
+"""UNet configuration, parameter enumeration and the synthetic-weight generator.
+
+No SD-1.5 weights exist offline, so benchmarks and parity tests run on
+SD-1.5-SHAPED weights drawn from a fixed seed; a local diffusers ``unet`` directory can be
+loaded instead when a box has one (``load_unet_state_dict``).  Names and layouts are those of
+diffusers' ``UNet2DConditionModel.state_dict()`` -- the same names libsdhip enumerates through
+``sd_unet_param_info`` (checked by tests/test_host_cpu.py).
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import torch
+
+
+@dataclass
+class UNetConfig:
+    """SD-1.5 UNet2DConditionModel config subset."""
+    sample_size: int = 64
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    attn_levels: Tuple[bool, ...] = (True, True, True, False)
+    cross_attention_dim: int = 768
+    num_heads: int = 8
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    context_len: int = 77
+    time_cond_proj_dim = None  # read by the reference loop at src/models.py:196
+
+
+def param_shapes(cfg: UNetConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(name, shape) of every UNet parameter in forward order."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    add = lambda n, s: out.append((n, tuple(s)))
+    c0 = cfg.block_out_channels[0]
+    temb = 4 * c0
+    nl = len(cfg.block_out_channels)
+
+    def resnet(p, cin, cout):
+        add(p + "norm1.weight", (cin,)); add(p + "norm1.bias", (cin,))
+        add(p + "conv1.weight", (cout, cin, 3, 3)); add(p + "conv1.bias", (cout,))
+        add(p + "time_emb_proj.weight", (cout, temb)); add(p + "time_emb_proj.bias", (cout,))
+        add(p + "norm2.weight", (cout,)); add(p + "norm2.bias", (cout,))
+        add(p + "conv2.weight", (cout, cout, 3, 3)); add(p + "conv2.bias", (cout,))
+        if cin != cout:
+            add(p + "conv_shortcut.weight", (cout, cin, 1, 1)); add(p + "conv_shortcut.bias", (cout,))
+
+    def transformer(p, c):
+        ctx = cfg.cross_attention_dim
+        add(p + "norm.weight", (c,)); add(p + "norm.bias", (c,))
+        add(p + "proj_in.weight", (c, c, 1, 1)); add(p + "proj_in.bias", (c,))
+        t = p + "transformer_blocks.0."
+        for i in (1, 2, 3):
+            add(t + f"norm{i}.weight", (c,)); add(t + f"norm{i}.bias", (c,))
+        add(t + "attn1.to_q.weight", (c, c)); add(t + "attn1.to_k.weight", (c, c)); add(t + "attn1.to_v.weight", (c, c))
+        add(t + "attn1.to_out.0.weight", (c, c)); add(t + "attn1.to_out.0.bias", (c,))
+        add(t + "attn2.to_q.weight", (c, c)); add(t + "attn2.to_k.weight", (c, ctx)); add(t + "attn2.to_v.weight", (c, ctx))
+        add(t + "attn2.to_out.0.weight", (c, c)); add(t + "attn2.to_out.0.bias", (c,))
+        add(t + "ff.net.0.proj.weight", (8 * c, c)); add(t + "ff.net.0.proj.bias", (8 * c,))
+        add(t + "ff.net.2.weight", (c, 4 * c)); add(t + "ff.net.2.bias", (c,))
+        add(p + "proj_out.weight", (c, c, 1, 1)); add(p + "proj_out.bias", (c,))
+
+    add("time_embedding.linear_1.weight", (temb, c0)); add("time_embedding.linear_1.bias", (temb,))
+    add("time_embedding.linear_2.weight", (temb, temb)); add("time_embedding.linear_2.bias", (temb,))
+    add("conv_in.weight", (c0, cfg.in_channels, 3, 3)); add("conv_in.bias", (c0,))
+    ch = c0
+    skip_ch = [c0]
+    for i in range(nl):
+        co = cfg.block_out_channels[i]
+        for j in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{i}.resnets.{j}.", ch, co)
+            ch = co
+            if cfg.attn_levels[i]:
+                transformer(f"down_blocks.{i}.attentions.{j}.", co)
+            skip_ch.append(co)
+        if i < nl - 1:
+            add(f"down_blocks.{i}.downsamplers.0.conv.weight", (co, co, 3, 3))
+            add(f"down_blocks.{i}.downsamplers.0.conv.bias", (co,))
+            skip_ch.append(co)
+    resnet("mid_block.resnets.0.", ch, ch)
+    transformer("mid_block.attentions.0.", ch)
+    resnet("mid_block.resnets.1.", ch, ch)
+    for i in range(nl):
+        lev = nl - 1 - i
+        co = cfg.block_out_channels[lev]
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"up_blocks.{i}.resnets.{j}.", ch + skip_ch.pop(), co)
+            ch = co
+            if cfg.attn_levels[lev]:
+                transformer(f"up_blocks.{i}.attentions.{j}.", co)
+        if i < nl - 1:
+            add(f"up_blocks.{i}.upsamplers.0.conv.weight", (co, co, 3, 3))
+            add(f"up_blocks.{i}.upsamplers.0.conv.bias", (co,))
+    add("conv_norm_out.weight", (c0,)); add("conv_norm_out.bias", (c0,))
+    add("conv_out.weight", (cfg.out_channels, c0, 3, 3)); add("conv_out.bias", (cfg.out_channels,))
+    return out
+
+
+def make_synthetic_state_dict(cfg: UNetConfig, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """Seeded SD-1.5-shaped weights, fp32 values already on the bf16 grid.
+
+    Conv/linear weights ~ N(0, 1/fan_in) (unit gain, so activations stay O(1) through the
+    normalised blocks), biases ~ N(0, 0.05^2), norm gains 1 + N(0, 0.1^2), norm shifts
+    N(0, 0.1^2) (non-trivial affine so parity tests exercise it).  Rounding to bf16 here means
+    the CPU oracle and the HIP path consume bit-identical parameters.
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape in param_shapes(cfg):
+        leaf = name.rsplit(".", 2)[-2]
+        is_norm = leaf.startswith("norm") or leaf == "conv_norm_out"
+        if name.endswith(".bias"):
+            t = torch.randn(shape, generator=g) * (0.1 if is_norm else 0.05)
+        elif is_norm:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            fan_in = math.prod(shape[1:])
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        sd[name] = t.to(torch.bfloat16).float()
+    return sd
+
+
+def load_unet_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
+    """Load a LOCAL diffusers UNet (``<dir>/unet/diffusion_pytorch_model.safetensors``).
+    Never fetches: names that are not local directories raise."""
+    from safetensors.torch import load_file
+    for cand in (os.path.join(model_dir, "unet", "diffusion_pytorch_model.safetensors"),
+                 os.path.join(model_dir, "diffusion_pytorch_model.safetensors")):
+        if os.path.isfile(cand):
+            return {k: v.float() for k, v in load_file(cand).items()}
+    raise FileNotFoundError(
+        f"no local UNet weights under {model_dir!r}; model names are network fetches and are "
+        "unavailable offline -- use synthetic weights or point at a local diffusers directory")
