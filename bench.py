@@ -1,0 +1,182 @@
+"""Headline benchmark: 512x512 images/sec at 50 DDIM steps (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: a full 50-step DDIM sampling loop with CFG
+(guidance 7.5) for `--batch` images per GPU (default 8 = BASELINE configs[1], "SD-1.5 512x512, DDIM
+50 steps, batch=8 bf16 on 1xMI355X"), inputs resident in HBM.  With N > 1 every rank samples its
+own shard of the global batch (weak scaling, no data-path collective except ONE RCCL all-gather of
+the final latents per step).  Weights are SD-1.5-shaped synthetic (no checkpoints exist offline).
+
+The JSON line also carries
+  roofline     - the dominant kernel (implicit-GEMM 3x3 conv, ~50 % of UNet FLOPs): algorithmic
+                 FLOPs per launch / hipEvent-measured launch time vs the 2.5 PFLOP/s bf16 MFMA peak
+  cpu_baseline - the CPU oracle (PyTorch fp32 restatement of the reference loop) timed on this
+                 box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_SAMPLE_FWD = 803.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed sampling runs (K)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed sampling runs (W)")
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per run")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--scheduler", default="ddim", choices=["ddim", "dpm", "lcm"])
+    ap.add_argument("--cache-interval", type=int, default=0, help="DeepCache interval (0 = off)")
+    ap.add_argument("--sample-size", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, args):
+    """Oracle timed on the host cores on a bounded sample of configs[0] (B=1, DDIM, CFG)."""
+    from oracle.unet import UNetConfig as OC, unet_forward
+    from oracle.schedulers import DDIMOracle
+    import dataclasses
+    ocfg = OC(**dataclasses.asdict(cfg))
+    g = torch.Generator().manual_seed(29)
+    lat = torch.randn((1, 4, cfg.sample_size, cfg.sample_size), generator=g)
+    ctx = torch.randn((2, cfg.context_len, cfg.cross_attention_dim), generator=g)
+    sch = DDIMOracle()
+    sch.set_timesteps(args.ddim_steps)
+    n_done, t0 = 0, time.time()
+    with torch.no_grad():
+        for t in sch.timesteps:
+            e = unet_forward(sd, ocfg, torch.cat([lat, lat]), t, ctx)
+            u, c = e.chunk(2)
+            lat = sch.step(u + 7.5 * (c - u), t, lat)[0]
+            n_done += 1
+            if time.time() - t0 > args.cpu_seconds:
+                break
+    dt = time.time() - t0
+    per_step = dt / n_done
+    return {"value": 1.0 / (per_step * args.ddim_steps), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n_done} of {args.ddim_steps} DDIM steps (CFG pair UNet forward + step, batch 1, fp32 "
+                      f"PyTorch-CPU oracle) in {dt:.1f}s, extrapolated to {args.ddim_steps} steps"}
+
+
+def main():
+    args = parse()
+    from sonicdiffusionbayeslab_amd import dist as sdist
+    rank, local_rank, world = sdist.init_process_group("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sonicdiffusionbayeslab_amd.deepcache import DeepCacheSDHelper
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
+    from sonicdiffusionbayeslab_amd.registry import schedulers_registry
+    from sonicdiffusionbayeslab_amd.weights import UNetConfig, make_synthetic_state_dict
+
+    cfg = UNetConfig(sample_size=args.sample_size)
+    sd = make_synthetic_state_dict(cfg, seed=1234)
+    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd), source="synthetic(seed=1234)")
+    model.to(dev)
+    name = {"ddim": "ddim_scheduler", "dpm": "dpm_solver_scheduler", "lcm": "lcm_scheduler"}[args.scheduler]
+    model.scheduler = schedulers_registry[name].from_config(model.scheduler.config)
+    if args.cache_interval > 0:
+        h = DeepCacheSDHelper(pipe=model)
+        h.set_params(cache_interval=args.cache_interval, cache_branch_id=0)
+        h.enable()
+    guidance = 0.0 if args.scheduler == "lcm" else 7.5
+
+    # synthetic inputs, resident in HBM before the timed region; global draw sliced per rank
+    B = args.batch
+    gb = B * world
+    lo, hi = sdist.shard_range(gb, rank, world)
+    lat_all = sdist.global_latents(gb, 4, cfg.sample_size, seed=29)
+    g = torch.Generator().manual_seed(30)
+    pe_all = torch.randn((gb, cfg.context_len, cfg.cross_attention_dim), generator=g)
+    ne = torch.randn((1, cfg.context_len, cfg.cross_attention_dim), generator=g)
+    lat = lat_all[lo:hi].to(dev)
+    pe = pe_all[lo:hi].to(dev)
+    neg = ne.repeat(hi - lo, 1, 1).to(dev)
+
+    def one_run():
+        out, secs, _ = model(prompt_embeds=pe, negative_prompt_embeds=neg, latents=lat,
+                             num_inference_steps=args.ddim_steps, guidance_scale=guidance,
+                             output_type="latent", collect_x0=False)
+        return sdist.gather_latents(out.images, world, gb), secs
+
+    for _ in range(args.warmup):
+        one_run()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    loop_secs = 0.0
+    for _ in range(args.steps):
+        final, secs = one_run()
+        loop_secs += secs
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(final).all(), "non-finite latents"
+
+    res = {
+        "metric": "512x512 images/sec at 50 DDIM steps",
+        "value": gb * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SD-1.5 512x512 {args.scheduler.upper()} {args.ddim_steps} steps, CFG {guidance}, "
+                               f"batch={B}/GPU (BASELINE configs[1])" + (f", DeepCache N={args.cache_interval}" if args.cache_interval else ""),
+                   "global_batch": gb, "sample_size": cfg.sample_size, "parallelism": f"batch-shard x{world}",
+                   "weights": "SD-1.5-shaped synthetic seed 1234", "loop_only_s_per_image": loop_secs / (args.steps * B)},
+    }
+    ub = (2 if guidance > 1 else 1) * B
+    nfwd = args.ddim_steps
+    res["config"]["unet_tflops_effective"] = (GFLOP_PER_SAMPLE_FWD * (cfg.sample_size / 64.0) ** 2 * ub * nfwd * args.steps / elapsed / 1e3
+                                              if not args.cache_interval else None)
+
+    if rank == 0 and not args.no_roofline:
+        prof = model.unet.forward_profiled(lat, ub, 501.0)       # warm
+        prof = model.unet.forward_profiled(lat, ub, 501.0)
+        c3 = prof["conv3x3"]
+        ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<128,160,2,2,CONV,STD> (implicit-GEMM 3x3 conv)",
+                           "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                           "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
+                           "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
+        tot = sum(v["ms"] for v in prof.values())
+        res["kernel_breakdown"] = {
+            k: {"ms": round(v["ms"], 4), "launches": v["launches"], "share": round(v["ms"] / tot, 4),
+                "tflops": (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] and v["ms"] else None),
+                "alg_GBs": (round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None)}
+            for k, v in prof.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

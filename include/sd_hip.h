@@ -79,6 +79,15 @@ int sd_unet_forward(sd_unet* u, void* stream, const float* latents, int latent_b
                     float timestep, float* eps_out, void* workspace, long long workspace_bytes, int cache_mode,
                     int cache_branch_id);
 
+/* Measurement hook for bench.py: the same forward with a hipEvent pair around every launch.  Per
+ * op kind (0 sinusoid, 1 gemv, 2 conv_in, 3 groupnorm, 4 conv3x3, 5 gemm, 6 layernorm,
+ * 7 attention, 8 conv_out) it returns summed milliseconds, launch count, algorithmic FLOPs and
+ * algorithmic HBM bytes.  Synchronises the stream; never used inside a timed region. */
+int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                             float timestep, float* eps_out, void* workspace, long long workspace_bytes, int cache_mode,
+                             int cache_branch_id, double kind_ms[16], long long kind_launches[16],
+                             double kind_flops[16], double kind_bytes[16]);
+
 /* Debug/parity hook: copy a named intermediate (bf16 NHWC) of the LAST full forward into `out`
  * as fp32; names: "conv_in", "down0".."down3", "mid", "up0".."up3".  Synchronises the stream. */
 int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host_out, long long numel,

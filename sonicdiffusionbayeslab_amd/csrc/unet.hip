@@ -868,6 +868,69 @@ extern "C" int sd_unet_forward(sd_unet* u, void* stream, const float* latents, i
     return 0;
 }
 
+// algorithmic work of one op: flops for the contraction kernels, minimal HBM bytes for the rest
+static void op_work(const Op& o, double* flops, double* bytes) {
+    *flops = 0; *bytes = 0;
+    switch (o.kind) {
+        case OP_CONV3:
+        case OP_GEMM:
+            *flops = 2.0 * o.M * o.N * o.K;
+            *bytes = 2.0 * ((double)o.M * o.K + (double)o.N * o.K + (double)o.M * (o.epi ? o.N / 2 : o.N));
+            break;
+        case OP_ATTN:
+            *flops = 4.0 * o.B * o.heads * (double)o.Nq * o.Nk * o.D;
+            *bytes = 2.0 * o.B * o.heads * o.D * (2.0 * o.Nq + 2.0 * o.Nk);
+            break;
+        case OP_GN:
+            *bytes = 2.0 * 2.0 * o.B * (double)o.HW * (o.C1 + o.C2);   // read once + write once, bf16
+            break;
+        case OP_LN:
+            *bytes = 2.0 * 2.0 * (double)o.M * o.N;
+            break;
+        default:
+            break;
+    }
+}
+
+extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                                        float timestep, float* eps_out, void* workspace, long long workspace_bytes,
+                                        int cache_mode, int cache_branch_id, double kind_ms[16], long long kind_launches[16],
+                                        double kind_flops[16], double kind_bytes[16]) {
+    SD_REQUIRE(latents && eps_out && workspace && kind_ms && kind_launches && kind_flops && kind_bytes,
+               "forward_profiled: null argument");
+    SD_REQUIRE(latent_batch > 0 && unet_batch % latent_batch == 0, "forward_profiled: bad batch");
+    Plan* pl;
+    int rc = get_plan(u, unet_batch, cache_branch_id, &pl);
+    if (rc) return rc;
+    SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "forward_profiled: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> which;
+    for (size_t i = 0; i < pl->ops.size(); ++i) {
+        if (cache_mode == SD_CACHE_SKIP && pl->skipped[i]) continue;
+        hipEvent_t a, b;
+        SD_CHECK_HIP(hipEventCreate(&a));
+        SD_CHECK_HIP(hipEventCreate(&b));
+        SD_CHECK_HIP(hipEventRecord(a, st));
+        rc = run_op(u, *pl, pl->ops[i], (char*)workspace, latents, latent_batch, eps_out, timestep, st);
+        SD_CHECK_HIP(hipEventRecord(b, st));
+        ev.push_back(a); ev.push_back(b); which.push_back((int)i);
+        if (rc) break;
+    }
+    SD_CHECK_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 16; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; kind_flops[k] = 0; kind_bytes[k] = 0; }
+    for (size_t j = 0; j < which.size(); ++j) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1]);
+        const Op& o = pl->ops[which[j]];
+        double fl, by;
+        op_work(o, &fl, &by);
+        kind_ms[o.kind] += ms; kind_launches[o.kind] += 1; kind_flops[o.kind] += fl; kind_bytes[o.kind] += by;
+    }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
 extern "C" int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host_out, long long numel,
                                     void* workspace, int unet_batch, int cache_branch_id) {
     SD_REQUIRE(u && u->debug_taps, "debug_tensor: create the handle with SD_DEBUG_TAPS=1 in the environment");

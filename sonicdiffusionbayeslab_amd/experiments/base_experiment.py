@@ -1,0 +1,94 @@
+"""Harness base class with the reference's hook order and benchmark semantics
+(``src/experiments/base_experiment.py:18-163``): 7 ``setup_*`` hooks in fixed order, one shared
+``torch.Generator`` that is never reseeded, scheduler swap through the registry +
+``from_config``, ``generate()`` looping prompt batches through ``self.model(...)`` and feeding
+``time_metric``.  Quality metrics that need fetched models and the wandb logger are out of the
+hot-path scope; results go to stdout as JSON lines."""
+from __future__ import annotations
+
+import json
+from abc import ABC, abstractmethod
+from collections import defaultdict
+
+import torch
+
+from ..dataset import PromptDataset
+from ..registry import metrics_registry, models_registry, schedulers_registry
+
+
+class BaseMethod(ABC):
+    def __init__(self, config):
+        self.config = config
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.setup_exp_params()
+        self.setup_generator()
+        self.setup_model()
+        self.setup_scheduler()
+        self.setup_dataset()
+        self.setup_metrics()
+        self.setup_loggers()
+
+    @abstractmethod
+    def run_experiment(self):
+        pass
+
+    def setup_exp_params(self):
+        pass
+
+    def setup_generator(self):
+        # the reference seeds a device generator (:51-53); a CPU generator makes the initial latents
+        # identical for every world size and box
+        self.generator = torch.Generator(device="cpu")
+        self.generator.manual_seed(self.config.experiment.seed)
+
+    def setup_model(self):
+        model_name = self.config.model.model_name
+        self.model = models_registry[model_name].from_pretrained(
+            self.config.model.pretrained_model,
+            timestamps=self.config.model.get("timestamps", None),
+            safety_checker=None,
+            requires_safety_checker=False,
+            torch_dtype=torch.float16,
+        )
+        self.model.to(self.device)
+
+    def setup_scheduler(self, **kwargs):
+        scheduler_name = self.config.scheduler.scheduler_name
+        self.model.scheduler = schedulers_registry[scheduler_name].from_config(self.model.scheduler.config, **kwargs)
+
+    def setup_dataset(self):
+        self.test_dataset = PromptDataset(self.config.dataset.img_dataset, self.config.dataset.prompts)
+
+    def setup_metrics(self):
+        self.metric_dict = defaultdict(list)
+        self.time_metric = metrics_registry["time_metric"]()
+
+    def setup_loggers(self):
+        self.logger = None
+
+    def generate(self, test_dataloader, steps: int, batch_size: int = 1, guidance_scale: float = 7.5):
+        gen_images_list, x0_preds = [], []
+        for idx, batch in enumerate(test_dataloader):
+            bc = self.config.inference.get("batch_count", None)
+            if bc is not None and idx >= bc:
+                break
+            imgs, inference_time, x0_preds = self.model(
+                batch["prompt"], num_inference_steps=steps, guidance_scale=guidance_scale,
+                generator=self.generator, output_type=self.config.inference.get("output_type", "latent"))
+            imgs = imgs.images.cpu()
+            gen_images_list.extend(imgs[i] for i in range(imgs.shape[0]))
+            self.time_metric.update(inference_time, batch_size)          # configured size, as :161
+        return gen_images_list, x0_preds
+
+    def validate(self, name_images, additional_values=None, n_images=0):
+        """Only the hot-path metric survives: seconds / image over the loop (``time_metric``)."""
+        if additional_values:
+            for k, v in additional_values.items():
+                self.metric_dict[k].append(v)
+        t = float(self.time_metric.compute())
+        self.metric_dict["nfe"].append(self.model.num_timesteps)
+        self.metric_dict["time_metric"].append(t)
+        print(json.dumps({"experiment": self.config.experiment_name, "run": name_images, "nfe": self.model.num_timesteps,
+                          "images": n_images, "time_metric_s_per_image": t,
+                          "images_per_s": (1.0 / t if t > 0 else None), "weights": self.model.weights_source}), flush=True)
+        self.time_metric.reset()

@@ -1,0 +1,268 @@
+"""``StableDiffusionModel`` -- the reference's pipeline plugin over the MI355X-native kernels.
+
+Registered as ``models_registry["stable_diffusion_model"]`` like ``src/models.py:21`` of the
+reference and callable the same way (``src/models.py:23-29,32-335``):
+
+    images, execution_time, x0_preds = model(prompts, num_inference_steps=N, guidance_scale=7.5,
+                                             generator=g, output_type="pt")
+
+The denoising loop (``src/models.py:210-282``) is restated with three changes that are the
+point of this framework: the UNet forward is libsdhip (hand-written gfx950 kernels), the CFG
+duplication is fused into conv_in, and CFG-combine + ``scheduler.step`` is one fused launch.
+Timing keeps the reference's definition -- wall-clock of the loop only (``:208,284-285``) -- but
+brackets it with device synchronisation so the number is real.
+
+Out of hot-path scope ("next" rows): the CLIP text encoder and the VAE decoder.
+Prompts are therefore encoded by a pluggable ``text_encoder`` (default: a deterministic seeded
+stand-in, since no CLIP weights exist offline) and ``output_type="latent"`` is the native
+output; ``"pt"`` needs a ``vae_decoder`` plugin.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import time
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from .registry import models_registry
+from .schedulers import PNDMConfigStub
+from .unet import CACHE_FULL_AND_STORE, CACHE_OFF, CACHE_SKIP, HipUNet2DConditionModel
+from .weights import UNetConfig, load_unet_state_dict, make_synthetic_state_dict
+
+
+@dataclass
+class StableDiffusionPipelineOutput:
+    images: torch.Tensor
+    nsfw_content_detected: Optional[list] = None
+
+
+class SyntheticTextEncoder:
+    """Deterministic stand-in for CLIP ViT-L/14 text encoding: a prompt's [77,768] embedding is
+    drawn ~N(0,1) from a generator seeded by the prompt's SHA-256.  Same prompt -> same
+    embedding on every rank and box; documented as synthetic in every report."""
+
+    def __init__(self, context_len: int = 77, dim: int = 768):
+        self.context_len, self.dim = context_len, dim
+        self._cache = {}
+
+    def __call__(self, prompts: List[str]) -> torch.Tensor:
+        out = []
+        for p in prompts:
+            if p not in self._cache:
+                seed = int.from_bytes(hashlib.sha256(p.encode("utf-8")).digest()[:8], "little") & (2 ** 63 - 1)
+                g = torch.Generator().manual_seed(seed)
+                self._cache[p] = torch.randn((self.context_len, self.dim), generator=g)
+            out.append(self._cache[p])
+        return torch.stack(out)
+
+
+class _VaeConfig:
+    scaling_factor = 0.18215
+
+
+@models_registry.add_to_registry("stable_diffusion_model")
+class StableDiffusionModel:
+    vae_scale_factor = 8
+
+    def __init__(self, unet_config: Optional[UNetConfig] = None, state_dict=None, scheduler=None,
+                 text_encoder: Optional[Callable] = None, vae_decoder: Optional[Callable] = None,
+                 weights_seed: int = 1234, source: str = "synthetic"):
+        self.unet_config = unet_config or UNetConfig()
+        self._state_dict = state_dict
+        self._weights_seed = weights_seed
+        self.weights_source = source
+        self.unet: Optional[HipUNet2DConditionModel] = None
+        self.scheduler = scheduler or PNDMConfigStub()
+        self.text_encoder = text_encoder or SyntheticTextEncoder(self.unet_config.context_len,
+                                                                 self.unet_config.cross_attention_dim)
+        self.vae_decoder = vae_decoder
+        self.vae_config = _VaeConfig()
+        self.device = torch.device("cpu")
+        self._num_timesteps = 0
+        self._guidance_scale = 7.5
+        self._deepcache = None          # set by DeepCacheSDHelper.enable()
+        self._lora = []
+
+    # -- loading ---------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, timestamps=None, safety_checker=None,
+                        requires_safety_checker=False, torch_dtype=None, **kwargs):
+        """``from_pretrained`` of the harness (``src/experiments/base_experiment.py:57-63``).
+
+        A local diffusers directory is loaded; a model NAME is a network fetch and cannot be
+        resolved offline, in which case SD-1.5-shaped synthetic weights seeded
+        by ``SD_AMD_WEIGHTS_SEED`` (default 1234) are used and ``weights_source`` says so."""
+        path = os.environ.get("SD_AMD_MODEL_DIR") or str(pretrained_model_name_or_path)
+        if os.path.isdir(path):
+            return cls(state_dict=load_unet_state_dict(path), source=f"local:{path}", **kwargs)
+        seed = int(os.environ.get("SD_AMD_WEIGHTS_SEED", "1234"))
+        return cls(weights_seed=seed, source=f"synthetic(seed={seed}) for {pretrained_model_name_or_path}", **kwargs)
+
+    def _ensure_unet(self):
+        if self.unet is None:
+            sd = self._state_dict or make_synthetic_state_dict(self.unet_config, self._weights_seed)
+            for (seed, scale, rank) in self._lora:
+                _fuse_synthetic_lora(sd, seed, scale, rank)
+            self.unet = HipUNet2DConditionModel(self.unet_config, sd, device="cuda:%d" % torch.cuda.current_device())
+            self._state_dict = None
+
+    def to(self, device):
+        """``model.to(device)`` (``base_experiment.py:64``; ``ddim.py:31,33``).  The UNet weights
+        live in HBM for the life of the object (1.7 GB of 288 GB); ``to("cpu")`` is a no-op."""
+        device = torch.device(device)
+        if device.type == "cuda":
+            self._ensure_unet()
+            self.device = self.unet.device
+        return self
+
+    # LCM-LoRA hooks used by src/experiments/consistency_model.py:20-21
+    def load_lora_weights(self, adapter_id, scale: float = 1.0, rank: int = 64):
+        if self.unet is not None:
+            raise RuntimeError("load_lora_weights must be called before the model is moved to the GPU")
+        seed = int.from_bytes(hashlib.sha256(str(adapter_id).encode()).digest()[:4], "little")
+        self._pending_lora = (seed, scale, rank)
+
+    def fuse_lora(self):
+        if getattr(self, "_pending_lora", None) is not None:
+            self._lora.append(self._pending_lora)
+            self._pending_lora = None
+
+    # -- properties the harness reads --------------------------------------------------------
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1 and self.unet_config.time_cond_proj_dim is None
+
+    # -- helpers of the loop -----------------------------------------------------------------
+    def encode_prompt(self, prompt, device, do_cfg, negative_prompt=None, prompt_embeds=None,
+                      negative_prompt_embeds=None):
+        if prompt_embeds is None:
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            prompt_embeds = self.text_encoder(prompts)
+        if do_cfg and negative_prompt_embeds is None:
+            n = prompt_embeds.shape[0]
+            neg = negative_prompt if negative_prompt is not None else [""] * n
+            neg = [neg] * n if isinstance(neg, str) else list(neg)
+            negative_prompt_embeds = self.text_encoder(neg)
+        to = lambda t: None if t is None else t.to(device, torch.float32)
+        return to(prompt_embeds), to(negative_prompt_embeds)
+
+    def prepare_latents(self, batch_size, num_channels, height, width, device, generator, latents=None):
+        shape = (batch_size, num_channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
+        latents = latents.to(device, torch.float32)
+        return (latents * self.scheduler.init_noise_sigma).contiguous()
+
+    def __call__(self, *args, return_execution_time=True, **kwargs):
+        result, execution_time, x0_preds = self.call(*args, **kwargs)
+        if return_execution_time:
+            return result, execution_time, x0_preds
+        return result, x0_preds
+
+    # -- the sampling loop (src/models.py:32-335) ----------------------------------------------
+    @torch.no_grad()
+    def call(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
+             num_inference_steps: int = 50, timesteps=None, sigmas=None, guidance_scale: float = 7.5,
+             negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None,
+             latents: Optional[torch.Tensor] = None, prompt_embeds: Optional[torch.Tensor] = None,
+             negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "pil",
+             return_dict: bool = True, guidance_rescale: float = 0.0, step_noise: Optional[torch.Tensor] = None,
+             collect_x0: bool = True, **kwargs):
+        if guidance_rescale != 0.0:
+            raise NotImplementedError("guidance_rescale is never used by the reference (src/models.py:53)")
+        if num_images_per_prompt != 1 or timesteps is not None or sigmas is not None:
+            raise NotImplementedError("custom timesteps / num_images_per_prompt are outside the reference's use")
+        self._ensure_unet()
+        device = self.unet.device
+        cfgu = self.unet_config
+        height = height or cfgu.sample_size * self.vae_scale_factor
+        width = width or cfgu.sample_size * self.vae_scale_factor
+        if height != cfgu.sample_size * 8 or width != cfgu.sample_size * 8:
+            raise ValueError("resolution is fixed by the UNet sample_size")
+        self._guidance_scale = guidance_scale
+
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None:
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+
+        do_cfg = self.do_classifier_free_guidance
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, device, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        ctx = torch.cat([negative_prompt_embeds, prompt_embeds]) if do_cfg else prompt_embeds   # :154-155
+        unet_batch = ctx.shape[0]
+
+        self.scheduler.set_timesteps(num_inference_steps, device=device)                        # :167-169
+        ts_host = list(self.scheduler._timesteps_list)
+        latents = self.prepare_latents(batch_size, cfgu.in_channels, height, width, device, generator, latents)
+
+        dc = self._deepcache
+        self.unet.set_deepcache(dc.cache_branch_id if dc is not None else -1)
+        self.unet.set_context(ctx)
+        eps = torch.empty((unet_batch, cfgu.out_channels, cfgu.sample_size, cfgu.sample_size),
+                          dtype=torch.float32, device=device)
+        self._num_timesteps = len(ts_host)
+        x0_preds = []
+        is_lcm = hasattr(self.scheduler, "config") and "timestep_scaling" in self.scheduler.config
+
+        torch.cuda.synchronize(device)
+        start_time = time.time()                                                                   # :208
+        for i, t in enumerate(ts_host):                                                            # :211
+            mode = CACHE_OFF
+            if dc is not None:
+                # DeepCache: index of t in scheduler.timesteps, first step always full (A.5)
+                cur = ts_host.index(t)
+                mode = CACHE_FULL_AND_STORE if (cur - 0) % dc.cache_interval == 0 else CACHE_SKIP
+            self.unet.forward_latents(latents, unet_batch, float(t), out=eps, cache_mode=mode)     # :217-235
+            kw = {}
+            if is_lcm and step_noise is not None and i < len(ts_host) - 1:
+                kw["noise"] = step_noise[i]
+            latents, x0 = self.scheduler.step_fused(eps, guidance_scale, latents, t, cfg=do_cfg,  # :238-261
+                                                    eta=eta, generator=generator, **kw)
+            if collect_x0:
+                x0_preds.append(x0[0:1])
+        torch.cuda.synchronize(device)
+        execution_time = time.time() - start_time                                                 # :284-285
+
+        if output_type == "latent":
+            image = latents
+            image_x0 = x0_preds
+        else:
+            if self.vae_decoder is None:
+                raise NotImplementedError(
+                    "VAE decode is a 'next' row outside the hot-path scope (SURVEY.md §8f.1): pass "
+                    "output_type='latent' or attach a vae_decoder plugin")
+            image = self.vae_decoder(latents / self.vae_config.scaling_factor)                    # :288
+            image = (image / 2 + 0.5).clamp(0, 1)                                                  # :312 postprocess("pt")
+            image_x0 = [(self.vae_decoder(x / self.vae_config.scaling_factor) / 2 + 0.5).clamp(0, 1) for x in x0_preds]
+        if not return_dict:
+            return (image, None), execution_time, image_x0
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0
+
+
+def _fuse_synthetic_lora(sd, seed: int, scale: float, rank: int):
+    """``fuse_lora``: W += scale * B @ A on the attention projections (A.6.3).  The LCM-LoRA
+    adapter is a network fetch (src/experiments/consistency_model.py:20), so a seeded synthetic
+    low-rank update of the same structure is fused instead."""
+    g = torch.Generator().manual_seed(seed)
+    for name in list(sd.keys()):
+        if any(k in name for k in (".to_q.weight", ".to_k.weight", ".to_v.weight", ".to_out.0.weight")):
+            w = sd[name]
+            o, i = w.shape
+            a = torch.randn((rank, i), generator=g) / (i ** 0.5)
+            b = torch.randn((o, rank), generator=g) * (0.02 / rank ** 0.5)
+            sd[name] = (w + scale * (b @ a)).to(torch.bfloat16).float()

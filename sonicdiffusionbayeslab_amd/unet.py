@@ -128,6 +128,23 @@ class HipUNet2DConditionModel:
                                              cache_mode, self.cache_branch_id), "sd_unet_forward")
         return out
 
+    KIND_NAMES = ("sinusoid", "gemv", "conv_in", "groupnorm", "conv3x3", "gemm", "layernorm", "attention", "conv_out")
+
+    def forward_profiled(self, latents: torch.Tensor, unet_batch: int, timestep: float, cache_mode: int = CACHE_OFF):
+        """One forward with a hipEvent pair around every launch (measurement only, synchronises).
+        Returns {kind: dict(ms, launches, flops, bytes)}."""
+        latents = latents.to(self.device, torch.float32).contiguous()
+        out = torch.empty((unet_batch, self.config.out_channels, latents.shape[2], latents.shape[3]),
+                          dtype=torch.float32, device=self.device)
+        ws = self._workspace(unet_batch)
+        ms, fl, by = (C.c_double * 16)(), (C.c_double * 16)(), (C.c_double * 16)()
+        ln = (C.c_longlong * 16)()
+        _lib.check(self._lib.sd_unet_forward_profiled(
+            self._handle, _lib.current_stream(), latents.data_ptr(), latents.shape[0], unet_batch, float(timestep),
+            out.data_ptr(), self._ws_ptr(ws), ws.numel() - 256, cache_mode, self.cache_branch_id, ms, ln, fl, by),
+            "sd_unet_forward_profiled")
+        return {n: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, n in enumerate(self.KIND_NAMES)}
+
     def __call__(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor = None,
                  timestep_cond=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict: bool = False,
                  **kwargs):
