@@ -15,6 +15,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int AMODE_GEMM = 0;
@@ -46,6 +48,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int split = bid / ntiles;
+    bid -= split * ntiles;
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -133,12 +138,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     const int xoff = (wm * WTM + lrow) * 128;
     const int woff = BM * 128 + (wn * WTN + lrow) * 128;
 
-    const int KT = p.K / 64;
-    stage(0, 0);
+    const int KTall = p.K / 64;
+    const int kt_begin = (int)((long)KTall * split / p.splitk);
+    const int KT = (int)((long)KTall * (split + 1) / p.splitk) - kt_begin;
+    stage(kt_begin, 0);
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < KT) stage(kt_begin + kt + 1, (kt + 1) & 1);
         const char* sb = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -156,7 +163,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     }
 
     // ---- epilogue: lane owns columns n..n+3 of row m for each 16x16 tile ----------------
-    if (EPI == EPI_STD) {
+    if (EPI == EPI_STD && p.splitk > 1) {
+        // split-K: raw fp32 partial sums into this split's slab; sd splitk_reduce finishes
+        float* slab = p.slab + (long)split * p.M * p.N;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wn * WTN + a * 16 + lq * 4;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * WTM + b * 16 + lrow;
+                if (m >= p.M) continue;
+                *(f32x4*)(slab + (long)m * p.N + n) = acc[a][b];
+            }
+        }
+    } else if (EPI == EPI_STD) {
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
             const int n = n0 + wn * WTN + a * 16 + lq * 4;
@@ -202,11 +223,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     }
 }
 
+// out[m, n..n+3] = sum_s slab[s][m][n..] + bias + bias2 + R   (deterministic split-K finish)
+__global__ void splitk_reduce_kernel(const GemmArgs p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = p.N / 4;
+    if (i >= (long)p.M * nq) return;
+    const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+    const long off = (long)m * p.N + n;
+    f32x4 v = *(const f32x4*)(p.slab + off);
+    for (int s = 1; s < p.splitk; ++s) v += *(const f32x4*)(p.slab + (long)s * p.M * p.N + off);
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    if (p.bias2) v += *(const f32x4*)(p.bias2 + n);
+    if (p.R) {
+        const u32x2 r = *(const u32x2*)(p.R + (long)m * p.ldr + n);
+        v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+    }
+    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
 int launch(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
+    if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
     constexpr int smem = 2 * (BM + BN) * 128;
     auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
     static bool attr_set = false;
@@ -214,13 +255,32 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    const int grid = a.tiles_m * a.tiles_n;
+    const int grid = a.tiles_m * a.tiles_n * a.splitk;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, stream, a);
+    if (a.splitk > 1) {
+        const long n4 = (long)a.M * (a.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a);
+    }
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
+
+// Split-K factor for a (M, N, K) problem on the 128x160 tile: only when the tile grid cannot fill
+// the 256 CUs and K is long enough to amortise the fp32 slab round trip.
+int sd_gemm_splitk(int M, int N, int K) {
+    static const char* env = getenv("SD_SPLITK");
+    if (env) return atoi(env) > 1 ? atoi(env) : 1;
+    const int tiles = ((M + 127) / 128) * ((N + 159) / 160);
+    const int KT = K / 64;
+    if (tiles >= 200) return 1;
+    int want = (512 + tiles - 1) / tiles;
+    int maxs = KT / 6;
+    int s = want < maxs ? want : maxs;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : s;
+}
 
 int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     SD_REQUIRE(a.K % 64 == 0 && a.K >= 64, "gemm: K=%d must be a positive multiple of 64", a.K);

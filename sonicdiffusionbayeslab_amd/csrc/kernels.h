@@ -21,10 +21,13 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     // conv geometry
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, stride = 1, up = 0;
+    int splitk = 1;                   // > 1: K is split over blocks, fp32 partials go through `slab`
+    float* slab = nullptr;            // [splitk, M, N] fp32 scratch (required when splitk > 1)
     const void* zero_page = nullptr;  // >= 16 zero bytes in device memory
     int tiles_m = 0, tiles_n = 0;     // filled by the launcher
 };
 
+int sd_gemm_splitk(int M, int N, int K);   // heuristic split factor (1 = none) for the std epilogue
 int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu*/, hipStream_t stream);
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
 
@@ -34,12 +37,13 @@ struct GroupNormArgs {
     const bf16_t* x2 = nullptr; int C2 = 0;   // optional
     const float* gamma = nullptr; const float* beta = nullptr;  // [C1+C2]
     bf16_t* y = nullptr;
-    float* partial = nullptr;   // workspace [B, nsplit, groups, 2] fp32
+    float* partial = nullptr;   // workspace of sd_groupnorm_scratch_bytes(): [B,nsplit,groups,2] partials + [B,groups,2] stats
     int B = 0, HW = 0, groups = 32, nsplit = 0;
     float eps = 1e-5f;
     int silu = 0;
 };
 int sd_groupnorm_nsplit(int B, int HW);
+size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups);
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream);
 
 int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,

@@ -43,8 +43,7 @@ __global__ void gn_stats_kernel(const GroupNormArgs a) {
     const int pbeg = split * per, pend = min(a.HW, pbeg + per);
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     if (active) {
-        for (int p = pbeg + prow; p < pend; p += g.rows_par) {
-            const u32x4 v = *(const u32x4*)gn_src(a, (long)b * a.HW + p, c0);
+        auto accum = [&](const u32x4 v) {
             float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]),
                           bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
 #pragma unroll
@@ -52,19 +51,39 @@ __global__ void gn_stats_kernel(const GroupNormArgs a) {
                 if (j < nb) { s0 += f[j]; q0 += f[j] * f[j]; }
                 else        { s1 += f[j]; q1 += f[j] * f[j]; }
             }
+        };
+        const long base = (long)b * a.HW;
+        const int rp = g.rows_par;
+        int p = pbeg + prow;
+        for (; p + 3 * rp < pend; p += 4 * rp) {   // 4 independent 16-B loads in flight per lane
+            const u32x4 v0 = *(const u32x4*)gn_src(a, base + p, c0);
+            const u32x4 v1 = *(const u32x4*)gn_src(a, base + p + rp, c0);
+            const u32x4 v2 = *(const u32x4*)gn_src(a, base + p + 2 * rp, c0);
+            const u32x4 v3 = *(const u32x4*)gn_src(a, base + p + 3 * rp, c0);
+            accum(v0); accum(v1); accum(v2); accum(v3);
         }
+        for (; p < pend; p += rp) accum(*(const u32x4*)gn_src(a, base + p, c0));
     }
     sh[tid] = make_float4(s0, q0, s1, q1);
     __syncthreads();
+    // deterministic two-level reduction: over the pixel rows of each chunk, then chunks -> groups
+    float4* sh2 = sh + blockDim.x;
+    if (tid < g.nchunks) {
+        float4 acc = sh[tid];
+        for (int r = 1; r < g.rows_par; ++r) {
+            const float4 v = sh[r * g.nchunks + tid];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        sh2[tid] = acc;
+    }
+    __syncthreads();
     if (tid < a.groups) {
+        const int c_lo = (tid * g.cpg) / 8, c_hi = ((tid + 1) * g.cpg - 1) / 8;
         float s = 0.f, q = 0.f;
-        const int nact = g.rows_par * g.nchunks;
-        for (int t = 0; t < nact; ++t) {       // fixed order -> bitwise reproducible
-            const int tc0 = (t % g.nchunks) * 8;
-            const int tg0 = tc0 / g.cpg, tg1 = (tc0 + 7) / g.cpg;
-            const float4 v = sh[t];
-            if (tg0 == tid) { s += v.x; q += v.y; }
-            if (tg1 == tid && tg1 != tg0) { s += v.z; q += v.w; }
+        for (int c = c_lo; c <= c_hi; ++c) {
+            const float4 v = sh2[c];
+            if ((c * 8) / g.cpg == tid) { s += v.x; q += v.y; }   // chunk's leading part is ours
+            else                        { s += v.z; q += v.w; }   // chunk straddles into our group
         }
         float* out = a.partial + (((long)b * a.nsplit + split) * a.groups + tid) * 2;
         out[0] = s;
@@ -72,38 +91,57 @@ __global__ void gn_stats_kernel(const GroupNormArgs a) {
     }
 }
 
+// one wave per (batch, group): sum the pixel-split partials -> mean, rstd
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= a.B * a.groups) return;
+    const int b = idx / a.groups, gi = idx - b * a.groups;
+    float s = 0.f, q = 0.f;
+    for (int i = lane; i < a.nsplit; i += 64) {
+        const float* pp = a.partial + (((long)b * a.nsplit + i) * a.groups + gi) * 2;
+        s += pp[0];
+        q += pp[1];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const float cnt = (float)a.HW * (float)((a.C1 + a.C2) / a.groups);
+        const float mean = s / cnt;
+        const float var = fmaxf(q / cnt - mean * mean, 0.f);
+        float* st = a.partial + (long)a.B * a.nsplit * a.groups * 2 + (long)idx * 2;
+        st[0] = mean;
+        st[1] = rsqrtf(var + a.eps);
+    }
+}
+
 __global__ void gn_apply_kernel(const GroupNormArgs a) {
-    __shared__ float mean_s[64], rstd_s[64];
     const GnGeom g = gn_geom(a.C1 + a.C2, a.groups);
     const int tid = threadIdx.x;
     const int split = blockIdx.x, b = blockIdx.y;
-    if (tid < a.groups) {
-        float s = 0.f, q = 0.f;
-        const float* pp = a.partial + ((long)b * a.nsplit * a.groups + tid) * 2;
-        for (int i = 0; i < a.nsplit; ++i) { s += pp[(long)i * a.groups * 2]; q += pp[(long)i * a.groups * 2 + 1]; }
-        const float cnt = (float)a.HW * (float)g.cpg;
-        const float mean = s / cnt;
-        const float var = fmaxf(q / cnt - mean * mean, 0.f);
-        mean_s[tid] = mean;
-        rstd_s[tid] = rsqrtf(var + a.eps);
-    }
-    __syncthreads();
     const bool active = tid < g.rows_par * g.nchunks;
     if (!active) return;
     const int prow = tid / g.nchunks, ch = tid - prow * g.nchunks;
     const int c0 = ch * 8;
+    const float* st = a.partial + (long)a.B * a.nsplit * a.groups * 2 + (long)b * a.groups * 2;
+    const int g0 = c0 / g.cpg, g1 = (c0 + 7) / g.cpg;
+    const int nb = min(8, (g0 + 1) * g.cpg - c0);
+    const float m0 = st[g0 * 2], r0 = st[g0 * 2 + 1], m1 = st[g1 * 2], r1 = st[g1 * 2 + 1];
     float sc[8], sf[8];
+    {
+        const f32x4 ga = *(const f32x4*)(a.gamma + c0), gb = *(const f32x4*)(a.gamma + c0 + 4);
+        const f32x4 ba = *(const f32x4*)(a.beta + c0), bb = *(const f32x4*)(a.beta + c0 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = c0 + j, gi = c / g.cpg;
-        sc[j] = rstd_s[gi] * a.gamma[c];
-        sf[j] = a.beta[c] - mean_s[gi] * sc[j];
+        for (int j = 0; j < 8; ++j) {
+            const float gm = j < 4 ? ga[j & 3] : gb[j & 3], bt = j < 4 ? ba[j & 3] : bb[j & 3];
+            const float mean = j < nb ? m0 : m1, rstd = j < nb ? r0 : r1;
+            sc[j] = rstd * gm;
+            sf[j] = bt - mean * sc[j];
+        }
     }
     const int per = (a.HW + a.nsplit - 1) / a.nsplit;
     const int pbeg = split * per, pend = min(a.HW, pbeg + per);
-    for (int p = pbeg + prow; p < pend; p += g.rows_par) {
-        const long pix = (long)b * a.HW + p;
-        const u32x4 v = *(const u32x4*)gn_src(a, pix, c0);
+    auto apply = [&](const u32x4 v, long pix) {
         float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]),
                       bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
 #pragma unroll
@@ -113,7 +151,18 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
         }
         u32x4 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
         *(u32x4*)(a.y + pix * g.C + c0) = o;
+    };
+    const long base = (long)b * a.HW;
+    const int rp = g.rows_par;
+    int p = pbeg + prow;
+    for (; p + 3 * rp < pend; p += 4 * rp) {
+        const u32x4 v0 = *(const u32x4*)gn_src(a, base + p, c0);
+        const u32x4 v1 = *(const u32x4*)gn_src(a, base + p + rp, c0);
+        const u32x4 v2 = *(const u32x4*)gn_src(a, base + p + 2 * rp, c0);
+        const u32x4 v3 = *(const u32x4*)gn_src(a, base + p + 3 * rp, c0);
+        apply(v0, base + p); apply(v1, base + p + rp); apply(v2, base + p + 2 * rp); apply(v3, base + p + 3 * rp);
     }
+    for (; p < pend; p += rp) apply(*(const u32x4*)gn_src(a, base + p, c0), base + p);
 }
 
 // one wave per token row; up to 3 chunks of 8 channels per lane (C <= 1536)
@@ -170,11 +219,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups) {
+    return ((size_t)B * sd_groupnorm_nsplit(B, HW) * groups * 2 + (size_t)B * groups * 2) * sizeof(float);
+}
+
 int sd_groupnorm_nsplit(int B, int HW) {
-    (void)B;
-    int n = HW / 64;
+    // enough blocks to cover 256 CUs several times over, but >= 8 pixels per block
+    int n = (2048 + B - 1) / B;
+    if (n > HW / 8) n = HW / 8;
     if (n < 1) n = 1;
-    if (n > 64) n = 64;
+    if (n > 256) n = 256;
     return n;
 }
 
@@ -188,7 +242,8 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
     dim3 grid(a.nsplit, a.B);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), g.threads * sizeof(float4), stream, a);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), (g.threads + g.nchunks) * sizeof(float4), stream, a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;

@@ -33,6 +33,21 @@ extern "C" const char* sd_last_error(void) { return g_err; }
 extern "C" int sd_abi_version(void) { return 1; }
 
 static void* g_zero_page = nullptr;
+// grow-only device scratch for the operator-level entry points (tests / micro-benchmarks only;
+// the UNet plan carries its own slabs inside the caller's workspace)
+static void* g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+static void* op_scratch(size_t bytes) {
+    if (bytes > g_scratch_bytes) {
+        (void)hipDeviceSynchronize();
+        if (g_scratch) (void)hipFree(g_scratch);
+        g_scratch = nullptr;
+        g_scratch_bytes = 0;
+        if (hipMalloc(&g_scratch, bytes) != hipSuccess) return nullptr;
+        g_scratch_bytes = bytes;
+    }
+    return g_scratch;
+}
 static int ensure_zero_page() {
     if (g_zero_page) return 0;
     SD_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
@@ -78,7 +93,7 @@ struct Op {
     float eps = 0.f;
     int heads = 0, D = 0, Nq = 0, Nk = 0;
     long ldq = 0, ldk = 0, ldv = 0, ldo = 0, qoff = 0, koff = 0, voff = 0;
-    int silu_in = 0;
+    int silu_in = 0, splitk = 1;
     int nwrap = 0;
     Wrap wraps[3];
 };
@@ -426,7 +441,7 @@ struct Builder {
         Op o; o.kind = OP_GN; o.x1 = x1; o.C1 = c1; o.x2 = x2; o.C2 = c2; o.HW = hw; o.B = UB;
         o.g = W(g); o.be = W(b); o.eps = eps; o.silu = silu;
         o.nsplit = sd_groupnorm_nsplit(UB, hw);
-        o.aux = tensor((size_t)UB * o.nsplit * u->cfg.norm_num_groups * 2 * 4);
+        o.aux = tensor(sd_groupnorm_scratch_bytes(UB, hw, u->cfg.norm_num_groups));
         o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
         push(o);
         return o.out;
@@ -439,6 +454,8 @@ struct Builder {
         o.Hout = o.Wout = (hv + 2 - 3) / stride + 1;
         o.M = UB * o.Hout * o.Wout; o.K = 9 * cin;
         o.w = W(w); o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
+        o.splitk = sd_gemm_splitk(o.M, o.N, o.K);
+        if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * o.M * o.N * 4);
         o.out = tensor((size_t)o.M * cout * 2);
         push(o);
         return o.out;
@@ -446,6 +463,8 @@ struct Builder {
     int gemm(int x1, int k1, int x2, int k2, int M, int N, const std::string& w, const std::string& b, int r, int epi) {
         Op o; o.kind = OP_GEMM; o.x1 = x1; o.x2 = x2; o.K1 = k1; o.K = k1 + k2; o.M = M; o.N = N; o.epi = epi;
         o.w = W(w); o.b = b.empty() ? NOFF : W(b); o.r = r;
+        o.splitk = epi ? 1 : sd_gemm_splitk(M, N, o.K);
+        if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * M * N * 4);
         o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
         push(o);
         return o.out;
@@ -708,7 +727,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out); a.ldc = o.N;
             a.M = o.M; a.N = o.N; a.K = o.K; a.K1 = o.K;
             a.Hin = o.Hin; a.Win = o.Win; a.Cin = o.Cin; a.Hout = o.Hout; a.Wout = o.Wout; a.stride = o.stride; a.up = o.up;
-            a.zero_page = g_zero_page;
+            a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
             return sd_launch_conv3x3(a, stream);
         }
         case OP_GEMM: {
@@ -716,7 +735,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.X = (const bf16_t*)T(o.x1); a.ldx = o.K1; a.X2 = (const bf16_t*)T(o.x2); a.ldx2 = o.K - o.K1; a.K1 = o.K1;
             a.W = (const bf16_t*)(wb + o.w); a.bias = o.b != NOFF ? (const float*)(wb + o.b) : nullptr;
             a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out); a.ldc = o.epi ? o.N / 2 : o.N;
-            a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page;
+            a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
             return sd_launch_gemm(a, o.epi, stream);
         }
         case OP_LN:
@@ -968,6 +987,11 @@ extern "C" int sd_op_gemm(void* stream, const void* X, long long ldx, const void
     a.X = (const bf16_t*)X; a.ldx = ldx; a.X2 = (const bf16_t*)X2; a.ldx2 = ldx2; a.K1 = K1;
     a.W = (const bf16_t*)W; a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = ldr;
     a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
+    a.splitk = epi ? 1 : sd_gemm_splitk(M, N, K);
+    if (a.splitk > 1) {
+        a.slab = (float*)op_scratch((size_t)a.splitk * M * N * 4);
+        SD_REQUIRE(a.slab, "sd_op_gemm: cannot allocate split-K scratch");
+    }
     return sd_launch_gemm(a, epi, (hipStream_t)stream);
 }
 
@@ -981,6 +1005,11 @@ extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const f
     a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = stride; a.up = upsample ? 1 : 0;
     a.Hout = ((Hin << a.up) + 2 - 3) / stride + 1; a.Wout = ((Win << a.up) + 2 - 3) / stride + 1;
     a.M = B * a.Hout * a.Wout; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page;
+    a.splitk = sd_gemm_splitk(a.M, a.N, a.K);
+    if (a.splitk > 1) {
+        a.slab = (float*)op_scratch((size_t)a.splitk * a.M * a.N * 4);
+        SD_REQUIRE(a.slab, "sd_op_conv3x3: cannot allocate split-K scratch");
+    }
     return sd_launch_conv3x3(a, (hipStream_t)stream);
 }
 
@@ -990,13 +1019,9 @@ extern "C" int sd_op_groupnorm(void* stream, const void* x1, int C1, const void*
     a.x1 = (const bf16_t*)x1; a.C1 = C1; a.x2 = (const bf16_t*)x2; a.C2 = C2; a.gamma = gamma; a.beta = beta;
     a.y = (bf16_t*)y; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
     a.nsplit = sd_groupnorm_nsplit(B, HW);
-    float* partial = nullptr;
-    SD_CHECK_HIP(hipMalloc((void**)&partial, (size_t)B * a.nsplit * groups * 2 * sizeof(float)));
-    a.partial = partial;
-    int rc = sd_launch_groupnorm(a, (hipStream_t)stream);
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(partial);
-    return rc;
+    a.partial = (float*)op_scratch(sd_groupnorm_scratch_bytes(B, HW, groups));
+    SD_REQUIRE(a.partial, "sd_op_groupnorm: cannot allocate scratch");
+    return sd_launch_groupnorm(a, (hipStream_t)stream);
 }
 
 extern "C" int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows,
