@@ -17,6 +17,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libsdhip.so")
 SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "small.hip", "unet.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "sd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# attention is VALU-bound: keep MFMA results in arch VGPRs (no v_accvgpr_read/write copies)
+# and let fmaxf lower to bare v_max/v_max3 (no canonicalising v_max x,x in front of each operand;
+# the kernel masks with -1e30, never with inf/NaN)
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"]}
 
 
 def _newer(a: str, b: str) -> bool:
@@ -35,7 +39,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

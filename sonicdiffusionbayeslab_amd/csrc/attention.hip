@@ -8,14 +8,22 @@
 // One workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries.
 //   S^T = K . Q^T   (v_mfma_f32_32x32x16_bf16, K rows as A operand, Q held in registers)
 // puts the query on the lane and 16 keys in the accumulator registers, so the online softmax
-// is lane-local (one cross-half exchange for the max and the final sum) and the bf16-packed
-// probabilities are directly the B operand of
+// is lane-local (one cross-half exchange for the max) and the bf16-packed probabilities are
+// directly the B operand of
 //   O^T += V^T . P^T
 // with no LDS round trip.  K rows are read in the order pi(r) = r with bits 2,3 swapped so the
 // accumulator-register -> k mapping of the second product meets V in natural key order; V^T
 // fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose).
-// K/V tiles (64 keys) are register-prefetched one tile ahead and staged in LDS with rows padded
-// to an odd number of 16-byte slots (conflict-free ds_read_b128 for the K fragments).
+//
+// The kernel is VALU-bound at d = 40 (exp + max + convert per score), so the design removes
+// vector instructions rather than matrix ones:
+//   * the softmax denominator is not summed on the VALU: the V tile carries a column of ones in
+//     its padding (d = 40 -> 64, 80 -> 96), so row D of O^T accumulates sum(P) on the matrix core;
+//   * 64 keys (two S^T tiles) share one max / rescale decision;
+//   * MFMA results live in arch VGPRs (built with -amdgpu-mfma-vgpr-form: no accvgpr copies);
+//   * per-thread staging offsets are loop invariant; K/V tiles are register-prefetched one tile
+//     ahead and double-buffered in LDS (one barrier per 64-key tile).
+// LDS rows are padded to an odd number of 16-byte slots (conflict-free ds_read_b128 K fragments).
 #include "common.h"
 #include "kernels.h"
 
@@ -25,19 +33,30 @@ namespace {
 
 __device__ __forceinline__ int pi_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
+template <int D>
+struct AttnCfg {
+    static constexpr int DK = (D + 15) / 16 * 16;          // QK^T contraction length (zero padded)
+    static constexpr int KQ = DK / 16;
+    static constexpr int DVT = (D + 31) / 32;              // 32-row O^T tiles
+    static constexpr int CH = D / 8;                       // 16-B chunks per K/V row
+    static constexpr int SLOTS = (DK > DVT * 32 ? DK : DVT * 32) / 8;
+    static constexpr int RS = (SLOTS | 1) * 16;            // LDS row stride (odd # of 16-B slots)
+    static constexpr int NPF = (64 * CH + 255) / 256;      // chunks each thread stages per tile
+    static constexpr bool ONES = DVT * 32 > D;             // room for the ones column
+    static constexpr bool DBUF = D <= 80;                  // double-buffered LDS tiles
+    static constexpr int TILE_BYTES = 2 * 64 * RS;         // K + V
+    static constexpr int SMEM = TILE_BYTES * (DBUF ? 2 : 1);
+    // waves per SIMD the register allocator must leave room for (one wave of a block per SIMD)
+    static constexpr int MIN_WAVES = D <= 40 ? 4 : (D <= 80 ? 3 : 2);
+};
+
 template <int D, bool USE_TR>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
-    constexpr int DK = (D + 15) / 16 * 16;
-    constexpr int KQ = DK / 16;
-    constexpr int DVT = (D + 31) / 32;
-    constexpr int CH = D / 8;
-    constexpr int SLOTS = (DK > DVT * 32 ? DK : DVT * 32) / 8;
-    constexpr int RS = (SLOTS | 1) * 16;         // LDS row stride in bytes (odd # of 16-B slots)
-    constexpr int NPF = (64 * CH + 255) / 256;   // 16-B chunks each thread prefetches per tile
+__global__ __launch_bounds__(256, AttnCfg<D>::MIN_WAVES) void attn_kernel(const AttnArgs a) {
+    using Cfg = AttnCfg<D>;
+    constexpr int KQ = Cfg::KQ, DVT = Cfg::DVT, CH = Cfg::CH, RS = Cfg::RS, NPF = Cfg::NPF;
+    constexpr bool ONES = Cfg::ONES, DBUF = Cfg::DBUF;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;
-    char* Vs = smem + 64 * RS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -46,8 +65,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const bool qvalid = q < a.Nq;
     const float c = a.scale * 1.4426950408889634f;
 
-    // ---- zero LDS once (pad columns stay zero for the whole kernel) ----
-    for (int i = tid; i < 2 * 64 * RS / 16; i += 256) *(u32x4*)(smem + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    // ---- zero LDS once (pad columns stay zero), then plant the ones column in every V row ----
+    for (int i = tid; i < Cfg::SMEM / 16; i += 256) *(u32x4*)(smem + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (ONES) {
+        for (int i = tid; i < 64 * (DBUF ? 2 : 1); i += 256) {
+            const int buf = i >> 6, key = i & 63;
+            *(bf16_t*)(smem + buf * Cfg::TILE_BYTES + 64 * RS + key * RS + D * 2) = 0x3F80;  // 1.0
+        }
+    }
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,h) holds Q[q][16kk + 8h .. +8) ----
     bf16x8 qf[KQ];
@@ -59,34 +85,47 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
             if (qvalid && col < D) qf[kk] = *(const bf16x8*)(qp + col);
             else qf[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
+        // Retire the Q loads HERE: otherwise hipcc's wait-count pass carries them as pending into
+        // the tile loop and puts s_waitcnt vmcnt(0) in front of the first MFMA of every iteration,
+        // which also drains the K/V prefetch issued a few instructions earlier.
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(qf[kk]));
     }
 
+    // ---- loop-invariant staging offsets ----
     const bf16_t* kbase = a.K + (long)b * a.Nk * a.ldk + head * D;
     const bf16_t* vbase = a.V + (long)b * a.Nk * a.ldv + head * D;
+    int st_key[NPF], st_lds[NPF];
+    long st_k[NPF], st_v[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int idx = tid + i * 256;
+        const int key = idx / CH, ch = idx - key * CH;
+        st_key[i] = idx < 64 * CH ? key : 1 << 28;      // out-of-range marker
+        st_lds[i] = key * RS + ch * 16;
+        st_k[i] = (long)key * a.ldk + ch * 8;
+        st_v[i] = (long)key * a.ldv + ch * 8;
+    }
     u32x4 kreg[NPF], vreg[NPF];
     auto prefetch = [&](int t) {
+        const int k0 = t * 64;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + i * 256;
-            const int key = idx / CH, ch = idx - key * CH;
-            const int gkey = t * 64 + key;
-            if (idx < 64 * CH && gkey < a.Nk) {
-                kreg[i] = *(const u32x4*)(kbase + (long)gkey * a.ldk + ch * 8);
-                vreg[i] = *(const u32x4*)(vbase + (long)gkey * a.ldv + ch * 8);
+            if (k0 + st_key[i] < a.Nk) {
+                kreg[i] = *(const u32x4*)(kbase + (long)k0 * a.ldk + st_k[i]);
+                vreg[i] = *(const u32x4*)(vbase + (long)k0 * a.ldv + st_v[i]);
             } else {
                 kreg[i] = u32x4{0u, 0u, 0u, 0u};
                 vreg[i] = u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](char* tile) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + i * 256;
-            const int key = idx / CH, ch = idx - key * CH;
-            if (idx < 64 * CH) {
-                *(u32x4*)(Ks + key * RS + ch * 16) = kreg[i];
-                *(u32x4*)(Vs + key * RS + ch * 16) = vreg[i];
+            if (st_key[i] < 64) {
+                *(u32x4*)(tile + st_lds[i]) = kreg[i];
+                *(u32x4*)(tile + 64 * RS + st_lds[i]) = vreg[i];
             }
         }
     };
@@ -101,90 +140,128 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const int kfrag_off = pi_swap23(r) * RS + h * 16;
     // transposed V read: lane 4q4+p4 of each 16-lane group addresses key row q4, 4 columns at 4*p4
     const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int vtr_off = (8 * h + q4) * RS + (16 * g16 + 4 * p4) * 2;
+    const int vtr_off = 64 * RS + (8 * h + q4) * RS + (16 * g16 + 4 * p4) * 2;
+
+    // one 64-key tile: two S^T tiles share the max / rescale decision
+    auto compute = [&](const char* tile, int key0) {
+        const bool two = key0 + 32 < a.Nk;          // second 32-key half has at least one key
+        f32x16 s0, s1;
+        {
+            const char* kp = tile + kfrag_off;
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp), qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+            for (int kk = 1; kk < KQ; ++kk)
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + kk * 32), qf[kk], s0, 0, 0, 0);
+            if (two) {
+                kp += 32 * RS;
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp), qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+                for (int kk = 1; kk < KQ; ++kk)
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + kk * 32), qf[kk], s1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s1[i] = -1e30f;
+            }
+        }
+        if (key0 + 64 > a.Nk) {                      // ragged tail: mask keys >= Nk
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kr = pi_swap23((i & 3) + 8 * (i >> 2) + 4 * h);
+                if (key0 + kr >= a.Nk) s0[i] = -1e30f;
+                if (key0 + 32 + kr >= a.Nk) s1[i] = -1e30f;
+            }
+        }
+        float tmax = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(s0[i], s1[i]));
+        {   // max across the two half-waves (the other 16+16 keys of the same query)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tmax),
+                                                             __builtin_bit_cast(unsigned, tmax), false, false);
+            tmax = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        const float m_new = fmaxf(m_run, tmax);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            if (!ONES) l_run *= alpha;
+#pragma unroll
+            for (int tt = 0; tt < DVT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[tt][i] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sv = s2 < 2 ? s0[8 * s2 + j] : s1[8 * (s2 - 2) + j];
+                p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -mc));
+                if (!ONES) l_run += p[j];
+            }
+            u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+            pf[s2] = __builtin_bit_cast(bf16x8, w);
+        }
+#pragma unroll
+        for (int tt = 0; tt < DVT; ++tt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                if (s2 >= 2 && !two) break;
+                bf16x8 vf;
+                if (USE_TR) {
+                    const char* ap = tile + s2 * 16 * RS + vtr_off + tt * 64;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(ap));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(ap + 4 * RS));
+                    vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        vf[j] = *(const short*)(tile + 64 * RS + (s2 * 16 + 8 * h + j) * RS + (32 * tt + r) * 2);
+                }
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[tt], 0, 0, 0);
+            }
+        }
+    };
 
     const int ntiles = (a.Nk + 63) / 64;
     prefetch(0);
-    __syncthreads();  // LDS zero fill done
-    for (int t = 0; t < ntiles; ++t) {
-        commit();
+    __syncthreads();  // LDS zero fill + ones column done
+    if (DBUF) {
+        commit(smem);
+        if (ntiles > 1) prefetch(1);
         __syncthreads();
-        if (t + 1 < ntiles) prefetch(t + 1);
-
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = t * 64 + sub * 32;
-            if (key0 >= a.Nk) break;
-            f32x16 s;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.f;
-            const char* kp = Ks + sub * 32 * RS + kfrag_off;
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(kp + kk * 32);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+        for (int t = 0; t < ntiles; ++t) {
+            char* cur = smem + (t & 1) * Cfg::TILE_BYTES;
+            if (t + 1 < ntiles) {
+                commit(smem + ((t + 1) & 1) * Cfg::TILE_BYTES);   // other buffer: last read in iteration t-1
+                if (t + 2 < ntiles) prefetch(t + 2);
             }
-            if (key0 + 32 > a.Nk) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key0 + pi_swap23(row) >= a.Nk) s[i] = -1e30f;
-                }
-            }
-            float tmax = s[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run, tmax);
-            if (!__all(m_new == m_run)) {
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-                l_run *= alpha;
-#pragma unroll
-                for (int tt = 0; tt < DVT; ++tt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[tt][i] *= alpha;
-                m_run = m_new;
-            }
-            const float mc = m_run * c;
-            float p[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -mc));
-                l_run += p[i];
-            }
-            bf16x8 pf[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 w = {pack2bf(p[8 * s2 + 0], p[8 * s2 + 1]), pack2bf(p[8 * s2 + 2], p[8 * s2 + 3]),
-                           pack2bf(p[8 * s2 + 4], p[8 * s2 + 5]), pack2bf(p[8 * s2 + 6], p[8 * s2 + 7])};
-                pf[s2] = __builtin_bit_cast(bf16x8, w);
-            }
-            const char* vp = Vs + sub * 32 * RS;
-#pragma unroll
-            for (int tt = 0; tt < DVT; ++tt) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 vf;
-                    if (USE_TR) {
-                        const char* ap = vp + s2 * 16 * RS + vtr_off + tt * 64;
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) bf16x4*)(ap));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) bf16x4*)(ap + 4 * RS));
-                        vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            vf[j] = *(const short*)(vp + (s2 * 16 + 8 * h + j) * RS + (32 * tt + r) * 2);
-                    }
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[tt], 0, 0, 0);
-                }
-            }
+            compute(cur, t * 64);
+            __syncthreads();
         }
-        __syncthreads();  // everyone done with this tile before it is overwritten
+    } else {
+        for (int t = 0; t < ntiles; ++t) {
+            commit(smem);
+            __syncthreads();
+            if (t + 1 < ntiles) prefetch(t + 1);
+            compute(smem, t * 64);
+            __syncthreads();  // everyone done with this tile before it is overwritten
+        }
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if (ONES) {
+        // row D of O^T holds sum(P): tile D/32, row D%32 = (reg&3) + 8*(reg>>2) + 4*h  ->  h = 0 half
+        constexpr int TT = D / 32, RR = D % 32;
+        static_assert(!ONES || ((RR & 4) == 0), "ones row must sit in the h = 0 half");
+        constexpr int REG = (RR & 3) + 4 * (RR >> 3);
+        l_tot = __shfl(o[TT][REG], r);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
     const float inv = 1.0f / l_tot;
     if (qvalid) {
         bf16_t* op = a.O + ((long)b * a.Nq + q) * a.ldo + head * D;
@@ -205,12 +282,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
-    constexpr int DK = (D + 15) / 16 * 16;
-    constexpr int DVT = (D + 31) / 32;
-    constexpr int SLOTS = (DK > DVT * 32 ? DK : DVT * 32) / 8;
-    constexpr int RS = (SLOTS | 1) * 16;
-    const int smem = 2 * 64 * RS;
+    const int smem = AttnCfg<D>::SMEM;
     static const bool no_tr = getenv("SD_ATTN_NO_TR") != nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
     dim3 grid((a.Nq + 127) / 128, a.heads, a.B);
     if (no_tr) hipLaunchKernelGGL((attn_kernel<D, false>), grid, dim3(256), smem, stream, a);
     else hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), smem, stream, a);
@@ -229,6 +308,7 @@ int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
                    a.ldo >= (long)a.heads * a.D, "attention: row stride smaller than heads*D");
     SD_REQUIRE(((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V) % 16 == 0 && (uintptr_t)a.O % 8 == 0,
                "attention: operands must be 16-byte aligned");
+    SD_REQUIRE(a.B <= 65535 && a.heads <= 65535, "attention: grid too large");
     switch (a.D) {
         case 40: return launch_attn<40>(a, stream);
         case 80: return launch_attn<80>(a, stream);

@@ -62,7 +62,10 @@ def main():
             print(f"conv res={res:3d} {cin:5d}->{cout:5d} s{stride} up{up}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
     if not args.only or "attn" in args.only:
         print("== attention ==")
-        for (hw, C, nk) in ((4096, 320, 0), (1024, 640, 0), (256, 1280, 0), (64, 1280, 0), (4096, 320, 77), (1024, 640, 77), (256, 1280, 77)):
+        shapes = ((4096, 320, 0), (1024, 640, 0), (256, 1280, 0), (64, 1280, 0), (4096, 320, 77), (1024, 640, 77), (256, 1280, 77))
+        if "attn0" in args.only:
+            shapes = shapes[:1]
+        for (hw, C, nk) in shapes:
             D = C // 8
             Nk = nk or hw
             q = rnd(UB, hw, C); kv = rnd(UB, Nk, 2 * C)
