@@ -109,7 +109,8 @@ int sd_sched_step(void* stream, const float* eps, int cfg, float guidance, const
 int sd_op_gemm(void* stream, const void* X, long long ldx, const void* X2, long long ldx2, int K1, const void* W,
                const float* bias, const float* bias2, const void* R, long long ldr, void* C, long long ldc, int M,
                int N, int K, int epi);
-/* NHWC 3x3 conv, pad 1, stride 1|2, optional fused nearest-2x upsample; W is [Cout][3][3][Cin] bf16 */
+/* NHWC 3x3 conv, pad 1, stride 1|2, optional fused nearest-2x upsample; W is bf16
+ * [Cout][Cin/64][3*3][64] (K runs over 64-channel slice, tap, channel) */
 int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2, const void* R,
                   void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample);
 int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,

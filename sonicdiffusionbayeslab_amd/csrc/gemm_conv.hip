@@ -4,7 +4,8 @@
 //
 // * X rows are either plain matrix rows (GEMM; optionally two K-segments from two tensors =
 //   a channel concat that is never materialised) or NHWC pixels gathered on the fly for a 3x3
-//   convolution (stride 1/2, optional fused nearest-2x upsample); K = 9*Cin ordered tap-major.
+//   convolution (stride 1/2, optional fused nearest-2x upsample); K = 9*Cin ordered
+//   (64-channel slice, tap, channel) so the 9 shifted reads of a slice are adjacent in time.
 // * Tiles are staged global -> LDS with 16-byte `global_load_lds` (no VGPR round trip), double
 //   buffered, one barrier per 64-deep K tile.  LDS rows are 128 B (64 bf16) with the 16-byte
 //   chunk index XOR-swizzled by (row & 7) -- applied on the per-lane SOURCE address, LDS stays
@@ -24,16 +25,27 @@ constexpr int AMODE_CONV = 1;
 constexpr int EPI_STD = 0;
 constexpr int EPI_GEGLU = 1;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// STAGES = 2: classic double buffer (wait for everything, one barrier per K tile).
+// STAGES = 3: two K tiles in flight; the wait before the barrier is a COUNTED vmcnt that leaves the
+//             newest tile's LDS-DMA outstanding, so HBM/L2 latency spans a whole tile of MFMA work.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int XI = BM / 8, WI = BN / 8;  // 1-KiB glds wave-instructions per tile
-    static_assert(XI % NW == 0 && WI % NW == 0, "tile rows must split evenly over waves");
-    constexpr int XPW = XI / NW, WPW = WI / NW;
+    static_assert(XI % NW == 0, "X tile rows must split evenly over waves");
+    constexpr int XPW = XI / NW;
+    constexpr int WPW = (WI + NW - 1) / NW;          // waves < WI % NW issue WPW, the rest WPW - 1
+    constexpr int WREM = WI % NW;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     static_assert(EPI != EPI_GEGLU || (TN % 2 == 0), "GEGLU pairs 16-col tiles");
+    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -59,22 +71,39 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     const int gch = (lane & 7) ^ lrow8;          // global 16-B chunk this lane fetches (swizzle)
     const char* zero = (const char*)p.zero_page;
 
-    int xrow[XPW];        // GEMM: global row or -1.  CONV: batch pixel base or -1
-    int xoy[XPW], xox[XPW];
+    // Everything that does not change along K is folded into one pointer per row here, so the
+    // per-tile work is a scalar offset add + a select (the K loop is otherwise address-VALU bound).
+    //   GEMM: row pointers into X (and X2 for the second K segment); null = zero page.
+    //   CONV: pointer of the tap (0,0) input pixel + a 9-bit validity mask of the taps.
+    const bf16_t* xptr[XPW];
+    const bf16_t* xptr2[XPW];
+    int xmask[XPW];
+    int xoy[XPW], xox[XPW], xb[XPW];   // only the fused-upsample conv path recomputes pixels per tap
+    const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
         const int inst = wave + i * NW;
         const int m = m0 + inst * 8 + lrow8;
+        xptr2[i] = nullptr; xmask[i] = 0; xoy[i] = xox[i] = xb[i] = 0;
         if (AMODE == AMODE_GEMM) {
-            xrow[i] = m < p.M ? m : -1;
-            xoy[i] = xox[i] = 0;
+            xptr[i] = m < p.M ? p.X + (long)m * p.ldx + gch * 8 : nullptr;
+            if (p.X2) xptr2[i] = m < p.M ? p.X2 + (long)m * p.ldx2 + gch * 8 : nullptr;
         } else {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            xrow[i] = m < p.M ? b * p.Hin * p.Win : -1;
-            xoy[i] = oy * p.stride - 1;
-            xox[i] = ox * p.stride - 1;
+            const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+            xoy[i] = y0; xox[i] = x0; xb[i] = m < p.M ? b * p.Hin * p.Win : -1;
+            xptr[i] = p.X + ((long)b * p.Hin * p.Win + (long)y0 * p.Win + x0) * p.Cin + gch * 8;
+            int mask = 0;
+            if (m < p.M) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ty = y0 + t / 3, tx = x0 + t % 3;
+                    if (ty >= 0 && ty < Hv && tx >= 0 && tx < Wv) mask |= 1 << t;
+                }
+            }
+            xmask[i] = mask;
         }
     }
     const bf16_t* wsrc[WPW];
@@ -82,46 +111,57 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     for (int i = 0; i < WPW; ++i) {
         const int inst = wave + i * NW;
         const int n = n0 + inst * 8 + lrow8;
-        wsrc[i] = n < p.N ? p.W + (long)n * p.K + gch * 8 : nullptr;
+        wsrc[i] = (inst < WI && n < p.N) ? p.W + (long)n * p.K + gch * 8 : nullptr;
     }
-    const int cpt = (AMODE == AMODE_CONV) ? p.Cin / 64 : 1;  // K tiles per tap
-    const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
 
+    // conv K order: k = (channel slice of 64, tap, channel) -- the 9 taps of one slice are
+    // consecutive K tiles, so the shifted re-reads of the same pixels hit L2 while still hot.
     auto stage = [&](int kt, int buf) {
         char* xs = smem + buf * STAGE_BYTES;
         char* ws = xs + BM * 128;
         const int k0 = kt * 64;
         if (AMODE == AMODE_GEMM) {
             const bool seg2 = k0 >= p.K1;
-            const bf16_t* base = seg2 ? p.X2 : p.X;
-            const long ld = seg2 ? p.ldx2 : p.ldx;
-            const int kk = (seg2 ? k0 - p.K1 : k0) + gch * 8;
+            const int kk = seg2 ? k0 - p.K1 : k0;
 #pragma unroll
             for (int i = 0; i < XPW; ++i) {
                 const int inst = wave + i * NW;
-                const void* src = xrow[i] >= 0 ? (const void*)(base + (long)xrow[i] * ld + kk) : (const void*)zero;
+                const bf16_t* rp = seg2 ? xptr2[i] : xptr[i];
+                const void* src = rp ? (const void*)(rp + kk) : (const void*)zero;
                 glds16(src, xs + inst * 1024);
             }
         } else {
-            const int tap = kt / cpt, cs = kt - tap * cpt;
+            const int cs = kt / 9, tap = kt - cs * 9;
             const int dy = tap / 3, dx = tap - dy * 3;
-            const int coff = cs * 64 + gch * 8;
+            if (!p.up) {
+                const long toff = ((long)dy * p.Win + dx) * p.Cin + cs * 64;   // wave-uniform
 #pragma unroll
-            for (int i = 0; i < XPW; ++i) {
-                const int inst = wave + i * NW;
-                const int ty = xoy[i] + dy, tx = xox[i] + dx;
-                const bool ok = xrow[i] >= 0 && ty >= 0 && ty < Hv && tx >= 0 && tx < Wv;
-                const int iy = ty >> p.up, ix = tx >> p.up;
-                const void* src = ok ? (const void*)(p.X + ((long)(xrow[i] + iy * p.Win + ix)) * p.Cin + coff)
-                                     : (const void*)zero;
-                glds16(src, xs + inst * 1024);
+                for (int i = 0; i < XPW; ++i) {
+                    const int inst = wave + i * NW;
+                    const void* src = ((xmask[i] >> tap) & 1) ? (const void*)(xptr[i] + toff) : (const void*)zero;
+                    glds16(src, xs + inst * 1024);
+                }
+            } else {
+                const int coff = cs * 64 + gch * 8;
+#pragma unroll
+                for (int i = 0; i < XPW; ++i) {
+                    const int inst = wave + i * NW;
+                    const int ty = xoy[i] + dy, tx = xox[i] + dx;
+                    const bool ok = (xmask[i] >> tap) & 1;
+                    const int iy = ty >> 1, ix = tx >> 1;
+                    const void* src = ok ? (const void*)(p.X + ((long)(xb[i] + iy * p.Win + ix)) * p.Cin + coff)
+                                         : (const void*)zero;
+                    glds16(src, xs + inst * 1024);
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int inst = wave + i * NW;
-            const void* src = wsrc[i] ? (const void*)(wsrc[i] + k0) : (const void*)zero;
-            glds16(src, ws + inst * 1024);
+            if (inst < WI) {     // wave-uniform
+                const void* src = wsrc[i] ? (const void*)(wsrc[i] + k0) : (const void*)zero;
+                glds16(src, ws + inst * 1024);
+            }
         }
     };
 
@@ -141,24 +181,62 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     const int KTall = p.K / 64;
     const int kt_begin = (int)((long)KTall * split / p.splitk);
     const int KT = (int)((long)KTall * (split + 1) / p.splitk) - kt_begin;
-    stage(kt_begin, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < KT) stage(kt_begin + kt + 1, (kt + 1) & 1);
-        const char* sb = smem + (kt & 1) * STAGE_BYTES;
+    // One K tile = two 32-deep k-steps.  The fragments of k-step 0 are read BEFORE the next tile's
+    // LDS-DMA is issued (a glds costs the issuing wave ~60 cycles each, which hides the ds_read
+    // latency), k-step 1's fragments are read under k-step 0's MFMAs.
+    bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    auto load_frags = [&](const char* sb, int ks, bf16x8* xf, bf16x8* wf) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[TM], wf[TN];
+        for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
 #pragma unroll
-            for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
+        for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8*)(sb + woff + t * 2048 + swz[ks]);
+    };
+    auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
 #pragma unroll
-            for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8*)(sb + woff + t * 2048 + swz[ks]);
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < TM; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    };
+
+    if (STAGES == 2) {
+        stage(kt_begin, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const char* sb = smem + (kt & 1) * STAGE_BYTES;
+            load_frags(sb, 0, xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < KT) stage(kt_begin + kt + 1, (kt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(sb, 1, xf1, wf1);
+            mfmas(xf0, wf0);
+            mfmas(xf1, wf1);
+        }
+    } else {
+        // loads this wave issues per K tile (wave-uniform): XPW + (wave < WREM ? WPW : WPW - 1)
+        const bool more = (WREM == 0) || (wave < WREM);
+        stage(kt_begin, 0);
+        if (KT > 1) stage(kt_begin + 1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) {           // leave tile kt+1 in flight
+                if (more) wait_vmcnt<XPW + WPW>();
+                else wait_vmcnt<XPW + WPW - 1>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; tile kt-1 fully consumed
+            asm volatile("" ::: "memory");
+            const char* sb = smem + buf * STAGE_BYTES;
+            load_frags(sb, 0, xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < KT) stage(kt_begin + kt + 2, buf == 0 ? 2 : buf - 1);   // reuses tile kt-1's buffer
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(sb, 1, xf1, wf1);
+            mfmas(xf0, wf0);
+            mfmas(xf1, wf1);
+            buf = buf == 2 ? 0 : buf + 1;
         }
     }
 
@@ -242,14 +320,15 @@ __global__ void splitk_reduce_kernel(const GemmArgs p) {
     *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI>
 int launch(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
-    constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, AMODE, EPI>;
+    constexpr int smem = STAGES * (BM + BN) * 128;
+    static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, AMODE, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -266,6 +345,16 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
 }
 
 }  // namespace
+
+// The 256-row, 8-wave, 3-stage (counted-vmcnt) tile, one workgroup per CU.  Measured on MI355X at
+// the SD-1.5 shapes it ties or loses to two independent 128-row workgroups per CU (its 8 waves
+// issue their LDS-DMA in lockstep after the barrier), so it is opt-in: SD_GEMM_BIG=1.
+static bool big_tile_ok(int M, int N, int BN) {
+    static const char* env = getenv("SD_GEMM_BIG");
+    if (env) return atoi(env) != 0;
+    (void)M; (void)N; (void)BN;
+    return false;
+}
 
 // Split-K factor for a (M, N, K) problem on the 128x160 tile: only when the tile grid cannot fill
 // the 256 CUs and K is long enough to amortise the fp32 slab round trip.
@@ -291,9 +380,11 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     SD_REQUIRE(a.zero_page != nullptr, "gemm: zero page missing");
     if (epi == EPI_GEGLU) {
         SD_REQUIRE(a.N % 32 == 0, "geglu gemm: N=%d must be a multiple of 32", a.N);
-        return launch<128, 128, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
+        if (big_tile_ok(a.M, a.N, 128)) return launch<256, 128, 4, 2, 3, AMODE_GEMM, EPI_GEGLU>(a, stream);
+        return launch<128, 128, 2, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
     }
-    return launch<128, 160, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
+    if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
+    return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
 }
 
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
@@ -308,5 +399,6 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
                "conv3x3: output size %dx%d inconsistent with input %dx%d stride %d up %d", a.Hout, a.Wout,
                a.Hin, a.Win, a.stride, a.up);
     SD_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "conv3x3: M not a multiple of Hout*Wout");
-    return launch<128, 160, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
+    if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_CONV, EPI_STD>(a, stream);
+    return launch<128, 160, 2, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
 }

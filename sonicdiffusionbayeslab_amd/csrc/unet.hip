@@ -274,7 +274,18 @@ struct Packer {
         unsigned short* o = (unsigned short*)(u->hblob.data() + off);
         for (size_t i = 0; i < d.size(); ++i) o[i] = f32_to_bf16_host(d[i]);
     }
-    void conv3(const std::string& n, int O, int I) {  // OIHW -> OHWI
+    // OIHW -> [O][I/64][tap][64]: K index = (64-channel slice, tap, channel) as the conv kernel walks it
+    void conv3(const std::string& n, int O, int I) {
+        const auto& d = P(n);
+        size_t off = alloc(n, d.size() * 2);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+        for (int oc = 0; oc < O; ++oc)
+            for (int ic = 0; ic < I; ++ic)
+                for (int t = 0; t < 9; ++t)
+                    o[(((size_t)oc * (I / 64) + ic / 64) * 9 + t) * 64 + (ic % 64)] =
+                        f32_to_bf16_host(d[((size_t)oc * I + ic) * 9 + t]);
+    }
+    void conv3_ohwi(const std::string& n, int O, int I) {  // OIHW -> [O][tap][I] (conv_out kernel)
         const auto& d = P(n);
         size_t off = alloc(n, d.size() * 2);
         unsigned short* o = (unsigned short*)(u->hblob.data() + off);
@@ -406,7 +417,7 @@ int pack_all(sd_unet* u) {
         pk.conv3(up + "weight", cu, cu); pk.f32(up + "bias");
     }
     pk.f32("conv_norm_out.weight"); pk.f32("conv_norm_out.bias");
-    pk.conv3("conv_out.weight", c.out_channels, c0); pk.f32("conv_out.bias");
+    pk.conv3_ohwi("conv_out.weight", c.out_channels, c0); pk.f32("conv_out.bias");
     return 0;
 }
 

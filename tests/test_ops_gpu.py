@@ -128,7 +128,7 @@ def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
         r = r16(torch.randn(B, Cout, Ho, Ho, generator=g))
         ref = ref + b2[None, :, None, None] + r
     xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
-    wd = dev(w.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    wd = dev(w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin // 64, 64).permute(0, 2, 1, 3).contiguous(), torch.bfloat16)
     rd = dev(r.permute(0, 2, 3, 1).contiguous(), torch.bfloat16) if extras else None
     out = torch.full((B, Ho, Ho, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
     _lib.check(sdlib.sd_op_conv3x3(stream(), P(xd), P(wd), P(b),

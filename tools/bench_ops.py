@@ -48,10 +48,13 @@ def main():
                 print(f"gemm {tag:6s} M={M:6d} N={N:5d} K={K:5d}  {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF/s")
     if not args.only or "conv" in args.only:
         print("== conv3x3 ==")
-        for (res, cin, cout, stride, up) in ((64, 320, 320, 1, 0), (64, 640, 320, 1, 0), (64, 960, 320, 1, 0),
-                                             (32, 640, 640, 1, 0), (32, 1280, 640, 1, 0), (32, 1920, 640, 1, 0),
-                                             (16, 1280, 1280, 1, 0), (16, 2560, 1280, 1, 0), (8, 1280, 1280, 1, 0),
-                                             (8, 2560, 1280, 1, 0), (64, 320, 320, 2, 0), (32, 640, 640, 1, 1)):
+        cshapes = ((64, 320, 320, 1, 0), (64, 640, 320, 1, 0), (64, 960, 320, 1, 0),
+                   (32, 640, 640, 1, 0), (32, 1280, 640, 1, 0), (32, 1920, 640, 1, 0),
+                   (16, 1280, 1280, 1, 0), (16, 2560, 1280, 1, 0), (8, 1280, 1280, 1, 0),
+                   (8, 2560, 1280, 1, 0), (64, 320, 320, 2, 0), (32, 640, 640, 1, 1))
+        if "conv0" in args.only:
+            cshapes = cshapes[1:2]
+        for (res, cin, cout, stride, up) in cshapes:
             x, w = rnd(UB, res, res, cin), rnd(cout, 3, 3, cin)
             ho = (res << up) // stride
             out = torch.empty(UB, ho, ho, cout, device="cuda", dtype=bf)
