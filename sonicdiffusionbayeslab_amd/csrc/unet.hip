@@ -794,8 +794,7 @@ extern "C" int sd_unet_create(const sd_unet_config* cfg, sd_unet** out) {
     SD_REQUIRE(cfg->cross_attention_dim % 64 == 0, "sd_unet_create: cross_attention_dim must be a multiple of 64");
     SD_REQUIRE(cfg->sample_size % (1 << (cfg->num_levels - 1)) == 0, "sd_unet_create: sample_size not divisible");
     SD_REQUIRE(cfg->context_len >= 1, "sd_unet_create: context_len");
-    if (ensure_zero_page()) return -2;
-    sd_unet* u = new sd_unet();
+    sd_unet* u = new sd_unet();   // no device work here: parameter enumeration also runs on a CPU-only box
     u->cfg = *cfg;
     u->debug_taps = getenv("SD_DEBUG_TAPS") != nullptr;
     enumerate_params(u);
@@ -836,6 +835,7 @@ extern "C" int sd_unet_finalize(sd_unet* u) {
     SD_REQUIRE(u, "finalize: null handle");
     SD_REQUIRE(!u->finalized, "finalize: already finalized");
     for (auto& p : u->params) SD_REQUIRE(p.loaded, "finalize: parameter '%s' was never loaded", p.name.c_str());
+    if (ensure_zero_page()) return -2;
     if (pack_all(u)) return -1;
     SD_CHECK_HIP(hipMalloc((void**)&u->dweights, u->hblob.size()));
     SD_CHECK_HIP(hipMemcpy(u->dweights, u->hblob.data(), u->hblob.size(), hipMemcpyHostToDevice));
