@@ -34,7 +34,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // STAGES = 3: two K tiles in flight; the wait before the barrier is a COUNTED vmcnt that leaves the
 //             newest tile's LDS-DMA outstanding, so HBM/L2 latency spans a whole tile of MFMA work.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -200,6 +200,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
     };
 
     if (STAGES == 2) {
+        // experiment knobs (SD_GEMM_TUNE): 1 = s_setprio around the MFMA clusters, 2 = half-tile start
+        // stagger for the second workgroup of a CU
+        if ((p.tune & 2) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
         stage(kt_begin, 0);
         for (int kt = 0; kt < KT; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,8 +213,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmA
             if (kt + 1 < KT) stage(kt_begin + kt + 1, (kt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             load_frags(sb, 1, xf1, wf1);
+            if (p.tune & 1) __builtin_amdgcn_s_setprio(1);
             mfmas(xf0, wf0);
             mfmas(xf1, wf1);
+            if (p.tune & 1) __builtin_amdgcn_s_setprio(0);
         }
     } else {
         // loads this wave issues per K tile (wave-uniform): XPW + (wave < WREM ? WPW : WPW - 1)
@@ -326,6 +331,8 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
+    static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
+    a.tune = tune;
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, AMODE, EPI>;

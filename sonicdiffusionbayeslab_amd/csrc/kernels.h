@@ -25,6 +25,7 @@ struct GemmArgs {
     float* slab = nullptr;            // [splitk, M, N] fp32 scratch (required when splitk > 1)
     const void* zero_page = nullptr;  // >= 16 zero bytes in device memory
     int tiles_m = 0, tiles_n = 0;     // filled by the launcher
+    int tune = 0;                     // experiment knobs, filled by the launcher from SD_GEMM_TUNE
 };
 
 int sd_gemm_splitk(int M, int N, int K);   // heuristic split factor (1 = none) for the std epilogue
