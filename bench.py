@@ -78,11 +78,15 @@ def cpu_baseline(cfg, sd, args):
 def main():
     args = parse()
     from sonicdiffusionbayeslab_amd import dist as sdist
-    rank, local_rank, world = sdist.init_process_group("nccl")
+    # SD_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N>1 code path (several ranks share cuda:0);
+    # the real run uses RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")
+    rank, local_rank, world = sdist.init_process_group(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from sonicdiffusionbayeslab_amd.deepcache import DeepCacheSDHelper
     from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
@@ -134,7 +138,7 @@ def main():
         torch.distributed.barrier()
     elapsed = time.time() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(final).all(), "non-finite latents"

@@ -48,6 +48,9 @@ def gather_latents(local: torch.Tensor, world: int, global_batch: int) -> torch.
     if world == 1:
         return local
     per = (global_batch + world - 1) // world
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:      # CPU rehearsal backend
+        local = local.cpu()
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = [torch.empty_like(pad) for _ in range(world)]
@@ -56,4 +59,4 @@ def gather_latents(local: torch.Tensor, world: int, global_batch: int) -> torch.
     for r in range(world):
         lo, hi = shard_range(global_batch, r, world)
         parts.append(out[r][: hi - lo])
-    return torch.cat(parts)
+    return torch.cat(parts).to(dev)
