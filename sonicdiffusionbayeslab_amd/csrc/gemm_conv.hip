@@ -25,6 +25,8 @@ constexpr int AMODE_CONV = 1;
 constexpr int EPI_STD = 0;
 constexpr int EPI_GEGLU = 1;
 
+constexpr int kPersistentGrid = 512;   // 2 workgroups per CU x 256 CUs
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -52,19 +54,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware tile order: blocks that share an XCD (same blockIdx % 8) get consecutive tiles,
-    // n fastest, so the X panel of one m-tile is re-read from that XCD's L2.
-    int bid = blockIdx.x;
+    // Persistent workgroups: the grid is at most 2 workgroups per CU and each walks the work items
+    // (output tile x K split) with stride gridDim.x.  XCD-aware order: blocks that share an XCD (same
+    // blockIdx % 8) get consecutive items, n fastest, so the X panel of an m-tile is re-read from
+    // that XCD's L2.  The first K tile of the NEXT item is prefetched before the epilogue of the
+    // current one, so neither the prologue latency nor the store tail is exposed between tiles.
+    int work = blockIdx.x;
     {
         const int nblk = gridDim.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int q = nblk >> 3, r = nblk & 7, xcd = work & 7, idx = work >> 3;
+        work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int split = bid / ntiles;
-    bid -= split * ntiles;
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nwork = ntiles * p.splitk;
+    const int KTall = p.K / 64;
+    int split = 0, m0 = 0, n0 = 0, kt_begin = 0, KT = 0;
+    auto decode = [&](int w) {
+        split = w / ntiles;
+        const int t = w - split * ntiles;
+        const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        kt_begin = (int)((long)KTall * split / p.splitk);
+        KT = (int)((long)KTall * (split + 1) / p.splitk) - kt_begin;
+        if (p.tune & 16) KT = 1;      // diagnostic build knob: epilogue + fixed costs only (wrong results)
+    };
 
     // ---- per-lane source descriptors -------------------------------------------------
     const int lrow8 = lane >> 3;                 // row inside an 8-row glds piece
@@ -79,7 +93,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     const bf16_t* xptr2[XPW];
     int xmask[XPW];
     int xoy[XPW], xox[XPW], xb[XPW];   // only the fused-upsample conv path recomputes pixels per tap
+    const bf16_t* wsrc[WPW];
     const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
+    auto setup = [&]() {
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
         const int inst = wave + i * NW;
@@ -106,13 +122,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             xmask[i] = mask;
         }
     }
-    const bf16_t* wsrc[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
         const int inst = wave + i * NW;
         const int n = n0 + inst * 8 + lrow8;
         wsrc[i] = (inst < WI && n < p.N) ? p.W + (long)n * p.K + gch * 8 : nullptr;
     }
+    };
 
     // conv K order: k = (channel slice of 64, tap, channel) -- the 9 taps of one slice are
     // consecutive K tiles, so the shifted re-reads of the same pixels hit L2 while still hot.
@@ -167,10 +183,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
 
     // ---- main loop ---------------------------------------------------------------------
     f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int lrow = lane & 15, lq = lane >> 4;
@@ -178,9 +190,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     const int xoff = (wm * WTM + lrow) * 128;
     const int woff = BM * 128 + (wn * WTN + lrow) * 128;
 
-    const int KTall = p.K / 64;
-    const int kt_begin = (int)((long)KTall * split / p.splitk);
-    const int KT = (int)((long)KTall * (split + 1) / p.splitk) - kt_begin;
     // One K tile = two 32-deep k-steps.  The fragments of k-step 0 are read BEFORE the next tile's
     // LDS-DMA is issued (a glds costs the issuing wave ~60 cycles each, which hides the ds_read
     // latency), k-step 1's fragments are read under k-step 0's MFMAs.
@@ -199,18 +208,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
     };
 
+    if (work >= nwork) return;
+    decode(work);
+    setup();
+    int g = 0;             // running K-tile count of this workgroup: LDS buffer parity (2-stage path)
+    bool primed = false;   // first K tile of the current item already in flight
+    bool stores_pending = false;   // ... and exactly EPI_STORES epilogue stores were issued after it
+    constexpr int EPI_STORES = (EPI == EPI_GEGLU ? TN / 2 : TN) * TM;   // per wave, full tile
+    while (true) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (STAGES == 2) {
-        // experiment knobs (SD_GEMM_TUNE): 1 = s_setprio around the MFMA clusters, 2 = half-tile start
-        // stagger for the second workgroup of a CU
-        if ((p.tune & 2) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
-        stage(kt_begin, 0);
+        if (!primed) stage(kt_begin, g & 1);
         for (int kt = 0; kt < KT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const char* sb = smem + (kt & 1) * STAGE_BYTES;
+            // vmcnt counts stores too and retires in order.  The first K tile of a prefetched item was
+            // issued BEFORE the previous item's epilogue stores, so a COUNTED wait (= that epilogue's
+            // store count) retires the DMA and leaves the stores in flight under this tile's MFMAs.
+            if (kt == 0 && stores_pending) wait_vmcnt<EPI_STORES>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* sb = smem + ((g + kt) & 1) * STAGE_BYTES;
             load_frags(sb, 0, xf0, wf0);
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < KT) stage(kt_begin + kt + 1, (kt + 1) & 1);
+            if (kt + 1 < KT) stage(kt_begin + kt + 1, (g + kt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             load_frags(sb, 1, xf1, wf1);
             if (p.tune & 1) __builtin_amdgcn_s_setprio(1);
@@ -218,6 +241,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             mfmas(xf1, wf1);
             if (p.tune & 1) __builtin_amdgcn_s_setprio(0);
         }
+        g += KT;
     } else {
         // loads this wave issues per K tile (wave-uniform): XPW + (wave < WREM ? WPW : WPW - 1)
         const bool more = (WREM == 0) || (wave < WREM);
@@ -244,18 +268,71 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             buf = buf == 2 ? 0 : buf + 1;
         }
     }
+    // ---- epilogue, phase A (before the next item's DMA is issued): every LOAD the epilogue needs --
+    // bias / time-embedding / residual are folded into the fp32 accumulators now, so that no ordinary
+    // load is outstanding once the LDS-DMA prefetch is in flight (hipcc would drain everything with
+    // vmcnt(0) at their first use) and phase B is stores only.
+    const int em0 = m0, en0 = n0, esplit = split;
+    if (p.splitk == 1) {
+        if (EPI == EPI_STD && p.R) {
+            // all residual loads of the tile issued back to back (rows clamped instead of branched, so
+            // the compiler keeps them in flight together), then folded into the accumulators
+            u32x2 rr[TN][TM];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = min(em0 + wm * WTM + b * 16 + lrow, p.M - 1);
+                    rr[a][b] = *(const u32x2*)(p.R + (long)m * p.ldr + n);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    acc[a][b][0] += bflo(rr[a][b][0]); acc[a][b][1] += bfhi(rr[a][b][0]);
+                    acc[a][b][2] += bflo(rr[a][b][1]); acc[a][b][3] += bfhi(rr[a][b][1]);
+                }
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                // (GEGLU keeps the packed [16 value | 16 gate] column order for its bias)
+                const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+                f32x4 bv = *(const f32x4*)(p.bias + n);
+                if (EPI == EPI_STD && p.bias2) bv += *(const f32x4*)(p.bias2 + n);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] += bv;
+            }
+        }
+    }
 
-    // ---- epilogue: lane owns columns n..n+3 of row m for each 16x16 tile ----------------
+    // ---- next work item: descriptors + first K tile in flight before the stores of this one -------
+    work += gridDim.x;
+    const bool more_work = work < nwork;
+    if (more_work) {
+        decode(work);
+        setup();
+        if (STAGES == 2) {       // buffer g&1 was last read two K tiles ago, before the last barrier
+            stage(kt_begin, g & 1);
+            primed = true;
+            // phase B issues exactly EPI_STORES stores per wave iff the finished tile is full
+            stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && !(p.tune & 32);
+        }
+    }
+
+    // ---- epilogue, phase B: convert + store; lane owns columns n..n+3 of row m per 16x16 tile -----
     if (EPI == EPI_STD && p.splitk > 1) {
-        // split-K: raw fp32 partial sums into this split's slab; sd splitk_reduce finishes
-        float* slab = p.slab + (long)split * p.M * p.N;
+        // split-K: raw fp32 partial sums into this split's slab; splitk_reduce_kernel finishes
+        float* slab = p.slab + (long)esplit * p.M * p.N;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + lq * 4;
+            const int n = en0 + wn * WTN + a * 16 + lq * 4;
             if (n >= p.N) continue;
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const int m = m0 + wm * WTM + b * 16 + lrow;
+                const int m = em0 + wm * WTM + b * 16 + lrow;
                 if (m >= p.M) continue;
                 *(f32x4*)(slab + (long)m * p.N + n) = acc[a][b];
             }
@@ -263,47 +340,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     } else if (EPI == EPI_STD) {
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + lq * 4;
+            const int n = en0 + wn * WTN + a * 16 + lq * 4;
             if (n >= p.N) continue;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv = *(const f32x4*)(p.bias + n);
-            if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const int m = m0 + wm * WTM + b * 16 + lrow;
+                const int m = em0 + wm * WTM + b * 16 + lrow;
                 if (m >= p.M) continue;
-                f32x4 v = acc[a][b] + bv;
-                if (p.R) {
-                    const u32x2 r = *(const u32x2*)(p.R + (long)m * p.ldr + n);
-                    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
-                }
+                const f32x4 v = acc[a][b];
                 u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+                if (!(p.tune & 8) || v[0] == 12345.f) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;   // tune 8: diagnostic, no stores
             }
         }
     } else {
         // GEGLU: weight rows were packed so that every 32-column group is [16 value | 16 gate]
 #pragma unroll
         for (int a = 0; a < TN; a += 2) {
-            const int n = n0 + wn * WTN + a * 16;  // first packed column of the pair
+            const int n = en0 + wn * WTN + a * 16;  // first packed column of the pair
             if (n >= p.N) continue;
             const int no = (n >> 1) + lq * 4;      // output column
-            f32x4 bva = {0.f, 0.f, 0.f, 0.f}, bvg = bva;
-            if (p.bias) {
-                bva = *(const f32x4*)(p.bias + n + lq * 4);
-                bvg = *(const f32x4*)(p.bias + n + 16 + lq * 4);
-            }
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const int m = m0 + wm * WTM + b * 16 + lrow;
+                const int m = em0 + wm * WTM + b * 16 + lrow;
                 if (m >= p.M) continue;
-                const f32x4 va = acc[a][b] + bva, vg = acc[a + 1][b] + bvg;
+                const f32x4 va = acc[a][b], vg = acc[a + 1][b];
                 u32x2 o = {pack2bf(va[0] * gelu_erf_f(vg[0]), va[1] * gelu_erf_f(vg[1])),
                            pack2bf(va[2] * gelu_erf_f(vg[2]), va[3] * gelu_erf_f(vg[3]))};
-                *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
+                if (!(p.tune & 8) || va[0] == 12345.f) *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
             }
         }
     }
+    if (!more_work) break;
+    if (STAGES != 2) __syncthreads();   // 3-stage path re-runs its prologue: all LDS reads must be done
+    }   // while (work)
 }
 
 // out[m, n..n+3] = sum_s slab[s][m][n..] + bias + bias2 + R   (deterministic split-K finish)
@@ -341,7 +409,8 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    const int grid = a.tiles_m * a.tiles_n * a.splitk;
+    int grid = a.tiles_m * a.tiles_n * a.splitk;
+    if (STAGES == 2 && grid > kPersistentGrid) grid = kPersistentGrid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, stream, a);
     if (a.splitk > 1) {
         const long n4 = (long)a.M * (a.N / 4);
