@@ -214,7 +214,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     int g = 0;             // running K-tile count of this workgroup: LDS buffer parity (2-stage path)
     bool primed = false;   // first K tile of the current item already in flight
     bool stores_pending = false;   // ... and exactly EPI_STORES epilogue stores were issued after it
-    constexpr int EPI_STORES = (EPI == EPI_GEGLU ? TN / 2 : TN) * TM;   // per wave, full tile
+    // stores per wave for a full tile: adjacent tiles are paired into 16-byte stores
+    constexpr int OUT_TILES = EPI == EPI_GEGLU ? TN / 2 : TN;
+    constexpr int EPI_STORES = (OUT_TILES / 2 + OUT_TILES % 2) * TM;
     while (true) {
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             stage(kt_begin, g & 1);
             primed = true;
             // phase B issues exactly EPI_STORES stores per wave iff the finished tile is full
-            stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && !(p.tune & 32);
+            stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && (p.ldc & 7) == 0 && p.splitk == 1 &&
+                             !(p.tune & (32 | 64 | 8));
         }
     }
 
@@ -338,34 +341,78 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             }
         }
     } else if (EPI == EPI_STD) {
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
+        // Stores are issue-bound (one 8-B store per lane per 16x16 tile): v_permlane16_swap pairs two
+        // adjacent tiles so that every lane owns 16 contiguous bytes -> half the store instructions,
+        // 64 contiguous bytes per row per instruction.  After the swap lane group lq holds
+        // lq=0: tile a cols 0-7, lq=1: tile a+1 cols 0-7, lq=2: tile a cols 8-15, lq=3: tile a+1 cols 8-15.
+        const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64);
+        auto store_narrow = [&](int a) {
             const int n = en0 + wn * WTN + a * 16 + lq * 4;
-            if (n >= p.N) continue;
+            if (n >= p.N) return;
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int m = em0 + wm * WTM + b * 16 + lrow;
-                if (m >= p.M) continue;
                 const f32x4 v = acc[a][b];
                 u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                if (!(p.tune & 8) || v[0] == 12345.f) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;   // tune 8: diagnostic, no stores
+                if (m < p.M && !(p.tune & 8)) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+            }
+        };
+#pragma unroll
+        for (int a = 0; a < TN; a += 2) {
+            const int nb = en0 + wn * WTN + a * 16;
+            if (a + 1 < TN && wide_ok && nb + 32 <= p.N) {            // wave-uniform: both tiles in range
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = em0 + wm * WTM + b * 16 + lrow;
+                    const f32x4 vx = acc[a][b], vy = acc[a + 1 < TN ? a + 1 : a][b];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
+                    const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
+                    if (m < p.M && !(p.tune & 8)) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+                }
+            } else {
+                store_narrow(a);
+                if (a + 1 < TN) store_narrow(a + 1);
             }
         }
     } else {
-        // GEGLU: weight rows were packed so that every 32-column group is [16 value | 16 gate]
-#pragma unroll
-        for (int a = 0; a < TN; a += 2) {
-            const int n = en0 + wn * WTN + a * 16;  // first packed column of the pair
-            if (n >= p.N) continue;
-            const int no = (n >> 1) + lq * 4;      // output column
+        // GEGLU: weight rows were packed so that every 32-column group is [16 value | 16 gate];
+        // two output tiles (four accumulator tiles) are paired for 16-byte stores as above
+        const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64);
+        auto geglu_tile = [&](int a, int b) -> u32x2 {      // output tile of accumulator pair (a, a+1)
+            const f32x4 va = acc[a][b], vg = acc[a + 1][b];
+            return u32x2{pack2bf(va[0] * gelu_erf_f(vg[0]), va[1] * gelu_erf_f(vg[1])),
+                         pack2bf(va[2] * gelu_erf_f(vg[2]), va[3] * gelu_erf_f(vg[3]))};
+        };
+        auto geglu_narrow = [&](int a) {
+            const int n = en0 + wn * WTN + a * 16;
+            if (n >= p.N) return;
+            const int no = (n >> 1) + lq * 4;
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int m = em0 + wm * WTM + b * 16 + lrow;
-                if (m >= p.M) continue;
-                const f32x4 va = acc[a][b], vg = acc[a + 1][b];
-                u32x2 o = {pack2bf(va[0] * gelu_erf_f(vg[0]), va[1] * gelu_erf_f(vg[1])),
-                           pack2bf(va[2] * gelu_erf_f(vg[2]), va[3] * gelu_erf_f(vg[3]))};
-                if (!(p.tune & 8) || va[0] == 12345.f) *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
+                const u32x2 o = geglu_tile(a, b);
+                if (m < p.M && !(p.tune & 8)) *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
+            }
+        };
+#pragma unroll
+        for (int a = 0; a < TN; a += 4) {
+            const int n = en0 + wn * WTN + a * 16;  // first packed column of the (pair of) pairs
+            if (a + 3 < TN && wide_ok && n + 64 <= p.N) {
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = em0 + wm * WTM + b * 16 + lrow;
+                    const u32x2 ox = geglu_tile(a, b), oy = geglu_tile(a + 2 < TN ? a + 2 : a, b);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ox[0], oy[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
+                    const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    const int col = (n >> 1) + (lq & 1) * 16 + (lq >> 1) * 8;
+                    if (m < p.M && !(p.tune & 8)) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+                }
+            } else {
+                geglu_narrow(a);
+                if (a + 2 < TN) geglu_narrow(a + 2);
             }
         }
     }
