@@ -95,14 +95,15 @@ int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host
 
 /* ---- fused CFG combine + scheduler.step (src/models.py:238-261; src/schedulers.py:98-187) ----
  *   eps   = cfg ? eps[0:n] + guidance*(eps[n:2n]-eps[0:n]) : eps[0:n]
- *   prev  = coef[0]*x + coef[1]*eps + coef[2]*m1 + coef[3]*m2 + coef[4]*noise
+ *   prev  = coef[0]*x + coef[1]*eps + coef[2]*m1 + coef[3]*m2 + coef[9]*m3 + coef[4]*noise
  *   y2    = coef[5]*x + coef[6]*eps      (x0_pred / LCM "denoised"), optional
  *   m_out = coef[7]*x + coef[8]*eps      (multistep history entry), optional
- * One launch serves DDIM, DPM-Solver / DPM-Solver++ (orders 1-3) and LCM; the host computes the
- * scalar coefficients from its sigma tables, so the kernel needs no host sync. */
+ * One launch serves DDIM, DPM-Solver / DPM-Solver++ (orders 1-3), LCM and PNDM/PLMS (4 history
+ * terms); the host computes the scalar coefficients from its sigma tables, so the kernel needs no
+ * host sync.  m1..m3, noise, y2, m_out may be NULL. */
 int sd_sched_step(void* stream, const float* eps, int cfg, float guidance, const float* x, const float* m1,
-                  const float* m2, const float* noise, float* prev, float* y2, float* m_out, const float coef[9],
-                  long long n);
+                  const float* m2, const float* m3, const float* noise, float* prev, float* y2, float* m_out,
+                  const float coef[10], long long n);
 
 /* ---- operator-level entry points (each is one hot kernel; used by the parity tests) ----------- */
 /* C[M,N] = [X|X2][M,K] . W[N,K]^T + bias + bias2 + R ; epi=1: GEGLU on interleaved W (N -> N/2) */

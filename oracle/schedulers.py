@@ -309,3 +309,64 @@ class LCMOracle(_Base):
             prev_sample = denoised
         self._step_index += 1
         return (prev_sample, denoised)
+
+
+class PNDMOracle(_Base):
+    """diffusers PNDMScheduler with ``skip_prk_steps=True`` (PLMS only) -- the checkpoint's own
+    scheduler, which the reference's ``deep_cache`` / ``default`` methods run because they never swap
+    it (``src/experiments/deep_cache.py:17-18``).  N steps -> N+1 UNet calls, the
+    second timestep is duplicated (A.7: 981, 961, 961, 941, ...)."""
+
+    def __init__(self, **config):
+        config.setdefault("skip_prk_steps", True)
+        super().__init__(**config)
+        self.final_alpha_cumprod = (torch.tensor(1.0) if self.config.get("set_alpha_to_one", False)
+                                    else self.alphas_cumprod[0])
+        self.ets = []
+        self.counter = 0
+        self.cur_sample = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config["num_train_timesteps"]
+        self.num_inference_steps = num_inference_steps
+        assert self.config.get("timestep_spacing", "leading") == "leading" and self.config["skip_prk_steps"]
+        step_ratio = T // num_inference_steps
+        _ts = (np.arange(0, num_inference_steps) * step_ratio).round() + self.config.get("steps_offset", 0)
+        plms = np.concatenate([_ts[:-1], _ts[-2:-1], _ts[-1:]])[::-1].copy()
+        self.timesteps = torch.from_numpy(plms.astype(np.int64))
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        alpha_prod_t = self.alphas_cumprod[timestep]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        beta_prod_t = 1 - alpha_prod_t
+        beta_prod_t_prev = 1 - alpha_prod_t_prev
+        sample_coeff = (alpha_prod_t_prev / alpha_prod_t) ** 0.5
+        denom = alpha_prod_t * beta_prod_t_prev ** 0.5 + (alpha_prod_t * beta_prod_t * alpha_prod_t_prev) ** 0.5
+        return sample_coeff * sample - (alpha_prod_t_prev - alpha_prod_t) * model_output / denom
+
+    def step(self, model_output, timestep, sample, return_dict=False, **kwargs):
+        timestep = int(timestep)
+        ratio = self.config["num_train_timesteps"] // self.num_inference_steps
+        prev_timestep = timestep - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        prev_sample = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return (prev_sample,)

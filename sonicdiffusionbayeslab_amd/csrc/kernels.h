@@ -76,10 +76,11 @@ int sd_launch_conv_out(const bf16_t* x, const bf16_t* Wp /*[Cout][9][Cin]*/, con
 
 // fused CFG combine + linear multistep scheduler update (DDIM / DPM-Solver(++) / LCM)
 struct StepCoef {
-    float px, pe, p1, p2, pn;  // prev = px*x + pe*eps + p1*m1 + p2*m2 + pn*noise
+    float px, pe, p1, p2, pn;  // prev = px*x + pe*eps + p1*m1 + p2*m2 + p3*m3 + pn*noise
     float yx, ye;              // y2   = yx*x + ye*eps           (x0_pred / denoised)
     float mx, me;              // m0   = mx*x + me*eps           (history entry)
+    float p3;                  // third history term (PNDM/PLMS order 4)
 };
 int sd_launch_sched_step(const float* eps, int cfg, float guidance, const float* x, const float* m1,
-                         const float* m2, const float* noise, float* prev, float* y2, float* m_out,
+                         const float* m2, const float* m3, const float* noise, float* prev, float* y2, float* m_out,
                          StepCoef c, long n, hipStream_t stream);

@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict_
 // ---- fused CFG + scheduler update ---------------------------------------------------------
 __global__ void sched_step_kernel(const float* __restrict__ eps, int cfg, float guidance,
                                   const float* __restrict__ x, const float* __restrict__ m1,
-                                  const float* __restrict__ m2, const float* __restrict__ noise,
-                                  float* __restrict__ prev, float* __restrict__ y2, float* __restrict__ m_out,
-                                  StepCoef c, long n4) {
+                                  const float* __restrict__ m2, const float* __restrict__ m3,
+                                  const float* __restrict__ noise, float* __restrict__ prev,
+                                  float* __restrict__ y2, float* __restrict__ m_out, StepCoef c, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     f32x4 e = ((const f32x4*)eps)[i];
@@ -139,6 +139,7 @@ __global__ void sched_step_kernel(const float* __restrict__ eps, int cfg, float 
     f32x4 p = c.px * xv + c.pe * e;
     if (m1) p += c.p1 * ((const f32x4*)m1)[i];
     if (m2) p += c.p2 * ((const f32x4*)m2)[i];
+    if (m3) p += c.p3 * ((const f32x4*)m3)[i];
     if (noise) p += c.pn * ((const f32x4*)noise)[i];
     if (y2) ((f32x4*)y2)[i] = c.yx * xv + c.ye * e;
     if (m_out) ((f32x4*)m_out)[i] = c.mx * xv + c.me * e;
@@ -204,13 +205,13 @@ int sd_launch_conv_out(const bf16_t* x, const bf16_t* Wp, const float* bias, flo
 }
 
 int sd_launch_sched_step(const float* eps, int cfg, float guidance, const float* x, const float* m1,
-                         const float* m2, const float* noise, float* prev, float* y2, float* m_out, StepCoef c,
-                         long n, hipStream_t stream) {
+                         const float* m2, const float* m3, const float* noise, float* prev, float* y2, float* m_out,
+                         StepCoef c, long n, hipStream_t stream) {
     SD_REQUIRE(eps && x && prev, "sched_step: null operand");
     SD_REQUIRE(n > 0 && n % 4 == 0, "sched_step: n=%ld must be a positive multiple of 4", n);
     const long n4 = n / 4;
     hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, eps, cfg, guidance,
-                       x, m1, m2, noise, prev, y2, m_out, c, n4);
+                       x, m1, m2, m3, noise, prev, y2, m_out, c, n4);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -982,11 +982,11 @@ extern "C" int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, 
 }
 
 extern "C" int sd_sched_step(void* stream, const float* eps, int cfg, float guidance, const float* x, const float* m1,
-                             const float* m2, const float* noise, float* prev, float* y2, float* m_out,
-                             const float coef[9], long long n) {
+                             const float* m2, const float* m3, const float* noise, float* prev, float* y2, float* m_out,
+                             const float coef[10], long long n) {
     SD_REQUIRE(coef, "sched_step: null coefficients");
-    StepCoef c{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8]};
-    return sd_launch_sched_step(eps, cfg, guidance, x, m1, m2, noise, prev, y2, m_out, c, (long)n, (hipStream_t)stream);
+    StepCoef c{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8], coef[9]};
+    return sd_launch_sched_step(eps, cfg, guidance, x, m1, m2, m3, noise, prev, y2, m_out, c, (long)n, (hipStream_t)stream);
 }
 
 // ---- operator-level entry points -------------------------------------------------------------

@@ -1,8 +1,8 @@
 """``methods_registry["deep_cache"]`` (``src/experiments/deep_cache.py:10-58``).
 
-The reference does not swap the scheduler here (``:17-18``) and so runs the checkpoint's PNDM,
-which is a "next" row; BASELINE config 4 quotes DeepCache on DDIM 50 steps, so
-the DDIM plugin is used unless the YAML names another scheduler."""
+The reference does not swap the scheduler here (``:17-18``) and so runs the checkpoint's PNDM:
+that is the default (``pndm_scheduler``); a ``scheduler.scheduler_name`` key in the YAML selects
+another plugin (BASELINE config 4 quotes DeepCache on DDIM 50 steps, see configs/deep_cache_config.yaml)."""
 from collections import defaultdict
 
 from ..deepcache import DeepCacheSDHelper
@@ -18,7 +18,7 @@ class DeepCacheMethod(BaseMethod):
         self.num_inference_steps = self.config.experiment_params.num_inference_steps
 
     def setup_scheduler(self):
-        name = self.config.get("scheduler", {}).get("scheduler_name", "ddim_scheduler")
+        name = self.config.get("scheduler", {}).get("scheduler_name", "pndm_scheduler")
         self.model.scheduler = schedulers_registry[name].from_config(self.model.scheduler.config)
 
     def run_experiment(self):

@@ -225,16 +225,20 @@ class StableDiffusionModel:
             mode = CACHE_OFF
             if dc is not None:
                 # DeepCache: index of t in scheduler.timesteps, first step always full (A.5)
-                cur = ts_host.index(t)
+                cur = ts_host.index(t)      # first match, as DeepCache's list.index (duplicate PNDM timestep quirk)
                 mode = CACHE_FULL_AND_STORE if (cur - 0) % dc.cache_interval == 0 else CACHE_SKIP
             self.unet.forward_latents(latents, unet_batch, float(t), out=eps, cache_mode=mode)     # :217-235
             kw = {}
             if is_lcm and step_noise is not None and i < len(ts_host) - 1:
                 kw["noise"] = step_noise[i]
-            latents, x0 = self.scheduler.step_fused(eps, guidance_scale, latents, t, cfg=do_cfg,  # :238-261
-                                                    eta=eta, generator=generator, **kw)
-            if collect_x0:
-                x0_preds.append(x0[0:1])
+            step = self.scheduler.step_fused(eps, guidance_scale, latents, t, cfg=do_cfg,          # :238-261
+                                             eta=eta, generator=generator, **kw)
+            if len(step) == 1:                                                                      # :257-261
+                latents = step[0]
+            else:
+                latents, x0 = step[0], step[1]
+                if collect_x0:
+                    x0_preds.append(x0[0:1])
         torch.cuda.synchronize(device)
         execution_time = time.time() - start_time                                                 # :284-285
 

@@ -5,6 +5,7 @@ Same registry keys, class names and call protocol as ``src/schedulers.py`` of th
 * ``"dpm_solver_scheduler"`` -> ``DPMSolverScheduler``  (``src/schedulers.py:12-187``)
 * ``"ddim_scheduler"``       -> ``DDIMSchedulerMy``     (``src/schedulers.py:190-192``)
 * ``"lcm_scheduler"``        -> ``LCMScheduler``        (``src/schedulers.py:195-197``)
+* ``"pndm_scheduler"``       -> ``PNDMScheduler``       (the checkpoint's own scheduler)
 
 Protocol kept: ``from_config(config, **overrides)``, ``.config``, ``.order``,
 ``.init_noise_sigma``, ``set_timesteps(n, device=)``, ``.timesteps``, ``scale_model_input``,
@@ -109,16 +110,18 @@ class _FusedStepScheduler:
 
     # --- the single fused launch ------------------------------------------------------------
     @staticmethod
-    def _launch(eps, cfg, guidance, x, m1, m2, noise, coef, want_y2=True, want_m=False):
+    def _launch(eps, cfg, guidance, x, m1, m2, noise, coef, want_y2=True, want_m=False, m3=None):
+        """coef = (px, pe, p1, p2, pn, yx, ye, mx, me[, p3]) -- see include/sd_hip.h::sd_sched_step."""
         lib = _lib.load()
         n = x.numel()
         prev = torch.empty_like(x)
         y2 = torch.empty_like(x) if want_y2 else None
         mo = torch.empty_like(x) if want_m else None
-        carr = (C.c_float * 9)(*[float(v) for v in coef])
+        c10 = [float(v) for v in coef] + [0.0] * (10 - len(coef))
+        carr = (C.c_float * 10)(*c10)
         _lib.check(lib.sd_sched_step(_lib.current_stream(), eps.data_ptr(), int(cfg), float(guidance), x.data_ptr(),
-                                     _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(noise), prev.data_ptr(), _lib.ptr(y2),
-                                     _lib.ptr(mo), carr, n), "sd_sched_step")
+                                     _lib.ptr(m1), _lib.ptr(m2), _lib.ptr(m3), _lib.ptr(noise), prev.data_ptr(),
+                                     _lib.ptr(y2), _lib.ptr(mo), carr, n), "sd_sched_step")
         return prev, y2, mo
 
     @staticmethod
@@ -402,11 +405,85 @@ class LCMScheduler(_FusedStepScheduler):
         return prev, den
 
 
+@schedulers_registry.add_to_registry("pndm_scheduler")
+class PNDMScheduler(_FusedStepScheduler):
+    """diffusers ``PNDMScheduler`` with ``skip_prk_steps=True`` (PLMS) -- the scheduler the SD-1.5
+    checkpoint ships and that the reference's ``deep_cache`` / ``default`` methods therefore run
+    (``src/experiments/deep_cache.py:17-18``, ``default_sd.py:15-16``).
+    N inference steps = N+1 UNet calls (second timestep duplicated).  Every PLMS update is a linear
+    combination of the sample, the current and up to three earlier noise predictions, so it runs on
+    the same fused kernel; ``step`` returns a 1-tuple like upstream."""
+    _own_defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                         trained_betas=None, skip_prk_steps=False, set_alpha_to_one=False, prediction_type="epsilon",
+                         timestep_spacing="leading", steps_offset=0)
+    _accepted = tuple(_own_defaults)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        if not self.config.skip_prk_steps or self.config.prediction_type != "epsilon" or \
+                self.config.timestep_spacing != "leading":
+            raise NotImplementedError("only the SD-1.5 PLMS configuration (skip_prk_steps, epsilon, leading) is built")
+        self.final_alpha_cumprod = 1.0 if self.config.set_alpha_to_one else float(self.alphas_cumprod[0])
+        self.ets: List[torch.Tensor] = []
+        self.counter = 0
+        self.cur_sample = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        ratio = T // num_inference_steps
+        base = (np.arange(0, num_inference_steps) * ratio).round() + self.config.steps_offset
+        plms = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy().astype(np.int64)
+        self._set(plms, device)
+        self.num_inference_steps = num_inference_steps        # N, not len(timesteps) = N + 1
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def _prev_coefs(self, t: int, prev_t: int):
+        a_t = float(self.alphas_cumprod[t])
+        a_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self.final_alpha_cumprod
+        sample_coeff = math.sqrt(a_p / a_t)
+        denom = a_t * math.sqrt(1 - a_p) + math.sqrt(a_t * (1 - a_t) * a_p)
+        return sample_coeff, -(a_p - a_t) / denom
+
+    def step_fused(self, model_output, guidance_scale, sample, timestep, cfg=True, eta=0.0, generator=None):
+        if self.num_inference_steps is None:
+            raise ValueError("run set_timesteps first")
+        t = int(timestep)
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        prev_t = t - ratio
+        x = self._prep(sample)
+        e = self._prep(model_output)
+        hist = self.ets
+        if self.counter != 1:
+            n_hist = min(len(hist), 3)
+            w = {0: (1.0,), 1: (1.5, -0.5), 2: (23 / 12, -16 / 12, 5 / 12), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[n_hist]
+            sc, k = self._prev_coefs(t, prev_t)
+            ms = [hist[-1 - i] if i < n_hist else None for i in range(3)]
+            ws = [w[i + 1] if i < n_hist else 0.0 for i in range(3)]
+            prev, _, e_out = self._launch(e, cfg, guidance_scale, x, ms[0], ms[1], None,
+                                          (sc, k * w[0], k * ws[0], k * ws[1], 0, 0, 0, 0.0, 1.0, k * ws[2]),
+                                          want_y2=False, want_m=True, m3=ms[2])
+            self.ets = (hist + [e_out])[-4:]
+            if self.counter == 0:
+                self.cur_sample = x
+        else:
+            # second call (same timestep again): average with the first prediction, restart from cur_sample
+            sc, k = self._prev_coefs(t + ratio, t)
+            prev, _, _ = self._launch(e, cfg, guidance_scale, self.cur_sample, hist[-1], None, None,
+                                      (sc, 0.5 * k, 0.5 * k, 0, 0, 0, 0, 0, 0, 0), want_y2=False, want_m=False)
+            self.cur_sample = None
+        self.counter += 1
+        return (prev,)
+
+    def step(self, model_output, timestep, sample, return_dict: bool = False, **kwargs):
+        out_dtype = model_output.dtype
+        (prev,) = self.step_fused(model_output, 0.0, sample, timestep, cfg=False)
+        return (prev.to(out_dtype),)
+
+
 class PNDMConfigStub:
-    """Stands in for the checkpoint's own PNDM scheduler so that
-    ``schedulers_registry[name].from_config(model.scheduler.config)``
-    (``src/experiments/base_experiment.py:69-72``) sees the SD-1.5 scheduler config.  PNDM itself is
-    a "next" row and cannot step."""
+    """The checkpoint's scheduler config holder: ``from_config(model.scheduler.config)``
+    (``src/experiments/base_experiment.py:69-72``) reads the SD-1.5 PNDM config from it.  Call
+    ``PNDMScheduler.from_config(stub.config)`` to actually step with PNDM."""
     order = 1
     init_noise_sigma = 1.0
 
@@ -414,5 +491,5 @@ class PNDMConfigStub:
         self.config = SchedulerConfig(SD15_SCHEDULER_CONFIG)
 
     def set_timesteps(self, *a, **k):
-        raise NotImplementedError("PNDM is outside the hot-path scope (SURVEY.md §8f row 3); "
-                                  "swap in ddim_scheduler / dpm_solver_scheduler / lcm_scheduler")
+        raise NotImplementedError("this is only the checkpoint's scheduler CONFIG; build a scheduler with "
+                                  "schedulers_registry[...].from_config(model.scheduler.config)")

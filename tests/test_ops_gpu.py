@@ -256,16 +256,17 @@ def test_sched_step_kernel(sdlib):
     n = 2 * 4 * 16 * 16
     eps = torch.randn(2 * n, generator=g); x = torch.randn(n, generator=g)
     m1 = torch.randn(n, generator=g); m2 = torch.randn(n, generator=g); z = torch.randn(n, generator=g)
-    coef = [0.9, -0.3, 0.2, -0.1, 0.05, 1.3, -0.7, 0.4, 0.6]
+    m3 = torch.randn(n, generator=g)
+    coef = [0.9, -0.3, 0.2, -0.1, 0.05, 1.3, -0.7, 0.4, 0.6, 0.15]
     gs = 7.5
     e = eps[:n] + gs * (eps[n:] - eps[:n])
-    prev = coef[0] * x + coef[1] * e + coef[2] * m1 + coef[3] * m2 + coef[4] * z
+    prev = coef[0] * x + coef[1] * e + coef[2] * m1 + coef[3] * m2 + coef[9] * m3 + coef[4] * z
     y2 = coef[5] * x + coef[6] * e
     mo = coef[7] * x + coef[8] * e
     d = [dev(t) for t in (eps, x, m1, m2, z)]
     o = [torch.zeros(n, device="cuda") for _ in range(3)]
-    carr = (ctypes.c_float * 9)(*coef)
-    _lib.check(sdlib.sd_sched_step(stream(), P(d[0]), 1, gs, P(d[1]), P(d[2]), P(d[3]),
+    carr = (ctypes.c_float * 10)(*coef)
+    _lib.check(sdlib.sd_sched_step(stream(), P(d[0]), 1, gs, P(d[1]), P(d[2]), P(d[3]), P(m3),
                                    P(d[4]), P(o[0]), P(o[1]), P(o[2]), carr, n))
     torch.cuda.synchronize()
     for got, ref in zip(o, (prev, y2, mo)):
