@@ -79,6 +79,17 @@ int sd_unet_forward(sd_unet* u, void* stream, const float* latents, int latent_b
                     float timestep, float* eps_out, void* workspace, long long workspace_bytes, int cache_mode,
                     int cache_branch_id);
 
+/* ---- AutoencoderKL decoder: replaces `self.vae.decode(latents / scaling_factor)`
+ * (src/models.py:287-302).  `sd_vae` IS the `sd_unet` handle type: parameters are enumerated / loaded /
+ * finalised and the workspace is sized through the sd_unet_* functions above (diffusers AutoencoderKL
+ * names: post_quant_conv.*, decoder.*); cfg: sample_size = latent size, block_out_channels =
+ * 128,256,512,512, layers_per_block = 2, in_channels = 4, out_channels = 3, norm_num_groups = 32.
+ * decode: fp32 NCHW latents [batch,4,h,w] * latent_scale -> fp32 NCHW images [batch,3,8h,8w]. */
+typedef struct sd_unet sd_vae;
+int sd_vae_create(const sd_unet_config* cfg, sd_vae** out);
+int sd_vae_decode(sd_vae* v, void* stream, const float* latents, int batch, float latent_scale, float* images_out,
+                  void* workspace, long long workspace_bytes);
+
 /* Measurement hook for bench.py: the same forward with a hipEvent pair around every launch.  Per
  * op kind (0 sinusoid, 1 gemv, 2 conv_in, 3 groupnorm, 4 conv3x3, 5 gemm, 6 layernorm,
  * 7 attention, 8 conv_out) it returns summed milliseconds, launch count, algorithmic FLOPs and

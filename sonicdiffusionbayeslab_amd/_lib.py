@@ -52,6 +52,8 @@ _SIGS = {
     "sd_unet_forward": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _ll, _i, _i]),
     "sd_unet_forward_profiled": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _ll, _i, _i, C.POINTER(C.c_double),
                                       C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sd_vae_create": (_i, [C.POINTER(SdUnetConfig), C.POINTER(_vp)]),
+    "sd_vae_decode": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _ll]),
     "sd_unet_debug_tensor": (_i, [_vp, _vp, C.c_char_p, _vp, _ll, _vp, _i, _i]),
     "sd_sched_step": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _ll]),
     "sd_op_gemm": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i]),

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     for (int i = 0; i < WPW; ++i) {
         const int inst = wave + i * NW;
         const int n = n0 + inst * 8 + lrow8;
-        wsrc[i] = (inst < WI && n < p.N) ? p.W + (long)n * p.K + gch * 8 : nullptr;
+        wsrc[i] = (inst < WI && n < p.N) ? p.W + (long)n * p.ldw + gch * 8 : nullptr;
     }
     };
 
@@ -445,6 +445,7 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
+    if (a.ldw == 0) a.ldw = a.K;
     if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
     static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
     a.tune = tune;

@@ -11,7 +11,8 @@ struct GemmArgs {
     const bf16_t* X2 = nullptr;  // optional second K segment [M, K-K1] (channel concat), GEMM only
     long ldx2 = 0;
     int K1 = 0;                  // split point (== K when there is no second segment)
-    const bf16_t* W = nullptr;   // [N, K] row-major (conv: K = tap*Cin + cin)
+    const bf16_t* W = nullptr;   // [N, K] rows of stride ldw (conv: K = (slice, tap, channel))
+    long ldw = 0;                // 0 = K (dense); a larger stride lets W be a column slice of an activation
     const float* bias = nullptr;   // [N] fp32, optional
     const float* bias2 = nullptr;  // [N] fp32, optional (time-embedding projection)
     const bf16_t* R = nullptr;     // residual [M, ldr], optional
@@ -46,6 +47,12 @@ struct GroupNormArgs {
 int sd_groupnorm_nsplit(int B, int HW);
 size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups);
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream);
+
+// in-place row softmax of bf16 scores: p = softmax(scale * s) over `cols` (multiple of 8)
+int sd_launch_softmax_rows(bf16_t* s, long rows, int cols, float scale, hipStream_t stream);
+// VAE post_quant_conv: y[b,co,p] = sum_ci W[co,ci] * (x[b,ci,p] * in_scale) + bias[co]  (fp32 NCHW, 4 -> 4)
+int sd_launch_pqconv(const float* x, const float* W, const float* bias, float* y, int B, int HW, float in_scale,
+                     hipStream_t stream);
 
 int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
                         float eps, hipStream_t stream);

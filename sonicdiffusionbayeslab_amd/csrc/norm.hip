@@ -217,7 +217,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     }
 }
 
+// one wave per row; the row lives in registers (cols <= 4096)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ s, long rows, int cols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bf16_t* r = s + row * cols;
+    const int nchunks = cols >> 3;
+    const float c = scale * 1.4426950408889634f;
+    float f[8][8];
+    float mx = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            const u32x4 v = *(const u32x4*)(r + ch * 8);
+            f[i][0] = bflo(v[0]); f[i][1] = bfhi(v[0]); f[i][2] = bflo(v[1]); f[i][3] = bfhi(v[1]);
+            f[i][4] = bflo(v[2]); f[i][5] = bfhi(v[2]); f[i][6] = bflo(v[3]); f[i][7] = bfhi(v[3]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, f[i][j]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f[i][j] = __builtin_amdgcn_exp2f((f[i][j] - mx) * c); sum += f[i][j]; }
+        }
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunks) {
+            u32x4 o = {pack2bf(f[i][0] * inv, f[i][1] * inv), pack2bf(f[i][2] * inv, f[i][3] * inv),
+                       pack2bf(f[i][4] * inv, f[i][5] * inv), pack2bf(f[i][6] * inv, f[i][7] * inv)};
+            *(u32x4*)(r + ch * 8) = o;
+        }
+    }
+}
+
 }  // namespace
+
+int sd_launch_softmax_rows(bf16_t* s, long rows, int cols, float scale, hipStream_t stream) {
+    SD_REQUIRE(s && rows > 0, "softmax_rows: empty");
+    SD_REQUIRE(cols % 8 == 0 && cols > 0 && cols <= 4096, "softmax_rows: cols=%d must be a multiple of 8 and <= 4096", cols);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, s, rows, cols, scale);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups) {
     return ((size_t)B * sd_groupnorm_nsplit(B, HW) * groups * 2 + (size_t)B * groups * 2) * sizeof(float);
@@ -236,8 +288,9 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const int C = a.C1 + a.C2;
     SD_REQUIRE(a.x1 && a.y && a.gamma && a.beta && a.partial, "groupnorm: null operand");
     SD_REQUIRE(a.C1 % 8 == 0 && a.C2 % 8 == 0 && (a.C2 == 0 || a.x2), "groupnorm: C1=%d C2=%d must be multiples of 8", a.C1, a.C2);
-    SD_REQUIRE(a.groups > 0 && a.groups <= 64 && C % a.groups == 0 && C / a.groups >= 8,
-               "groupnorm: C=%d groups=%d needs C/groups >= 8", C, a.groups);
+    // an 8-channel chunk may straddle at most two groups: cpg >= 8, or cpg = 4 (aligned halves)
+    SD_REQUIRE(a.groups > 0 && a.groups <= 64 && C % a.groups == 0 && (C / a.groups >= 8 || C / a.groups == 4),
+               "groupnorm: C=%d groups=%d needs C/groups >= 8 (or == 4)", C, a.groups);
     SD_REQUIRE(a.nsplit >= 1 && a.nsplit <= a.HW && a.B > 0 && a.HW > 0, "groupnorm: bad split %d for HW=%d", a.nsplit, a.HW);
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);

@@ -154,7 +154,30 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __rest
     ((u32x2*)dst)[i] = o;
 }
 
+__global__ void pqconv_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                              float* __restrict__ y, int B, int HW, float in_scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW);
+    const long p = i - (long)b * HW;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = x[((long)b * 4 + c) * HW + p] * in_scale;
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+        y[((long)b * 4 + co) * HW + p] = bias[co] + W[co * 4 + 0] * v[0] + W[co * 4 + 1] * v[1] + W[co * 4 + 2] * v[2] + W[co * 4 + 3] * v[3];
+}
+
 }  // namespace
+
+int sd_launch_pqconv(const float* x, const float* W, const float* bias, float* y, int B, int HW, float in_scale,
+                     hipStream_t stream) {
+    SD_REQUIRE(x && W && bias && y && B > 0 && HW > 0, "pqconv: bad operand");
+    const long n = (long)B * HW;
+    hipLaunchKernelGGL(pqconv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, W, bias, y, B, HW, in_scale);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream) {
     SD_REQUIRE(src && dst && n > 0 && n % 4 == 0, "f32_to_bf16: n=%ld must be a positive multiple of 4", n);

@@ -80,7 +80,7 @@ struct Wrap {  // one DeepCache-wrapped module enclosing an op
     int block_i, layer_i;
 };
 
-enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT };
+enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT, OP_SOFTMAX, OP_PQCONV };
 
 struct Op {
     int kind = 0;
@@ -94,6 +94,12 @@ struct Op {
     int heads = 0, D = 0, Nq = 0, Nk = 0;
     long ldq = 0, ldk = 0, ldv = 0, ldo = 0, qoff = 0, koff = 0, voff = 0;
     int silu_in = 0, splitk = 1;
+    // generalised GEMM operands (VAE attention): W operand taken from an activation tensor, X taken
+    // from the weight blob, element offsets into tensors and explicit row strides
+    int wt = -1;
+    size_t wx = NOFF;
+    long xoff = 0, woff_el = 0, coff = 0, ldx_o = 0, ldw_o = 0, ldc_o = 0;
+    float scale = 0.f;
     int nwrap = 0;
     Wrap wraps[3];
 };
@@ -121,6 +127,7 @@ struct Plan {
 }  // namespace
 
 struct sd_unet {
+    int kind = 0;   // 0 = UNet2DConditionModel, 1 = AutoencoderKL decoder (sd_vae is the same handle type)
     sd_unet_config cfg;
     std::vector<ParamSpec> params;
     std::unordered_map<std::string, int> pindex;
@@ -242,6 +249,48 @@ void enumerate_params(sd_unet* u) {
     e.add("conv_norm_out.bias", {c0});
     e.add("conv_out.weight", {c.out_channels, c0, 3, 3});
     e.add("conv_out.bias", {c.out_channels});
+}
+
+// AutoencoderKL decoder (diffusers names): post_quant_conv + decoder.*  
+void enumerate_params_vae(sd_unet* u) {
+    const sd_unet_config& c = u->cfg;
+    Enum e{u};
+    const int nl = c.num_levels, top = c.block_out_channels[nl - 1];
+    auto resnet = [&](const std::string& p, int cin, int cout) {
+        e.add(p + "norm1.weight", {cin}); e.add(p + "norm1.bias", {cin});
+        e.add(p + "conv1.weight", {cout, cin, 3, 3}); e.add(p + "conv1.bias", {cout});
+        e.add(p + "norm2.weight", {cout}); e.add(p + "norm2.bias", {cout});
+        e.add(p + "conv2.weight", {cout, cout, 3, 3}); e.add(p + "conv2.bias", {cout});
+        if (cin != cout) { e.add(p + "conv_shortcut.weight", {cout, cin, 1, 1}); e.add(p + "conv_shortcut.bias", {cout}); }
+    };
+    e.add("post_quant_conv.weight", {c.in_channels, c.in_channels, 1, 1});
+    e.add("post_quant_conv.bias", {c.in_channels});
+    e.add("decoder.conv_in.weight", {top, c.in_channels, 3, 3});
+    e.add("decoder.conv_in.bias", {top});
+    resnet("decoder.mid_block.resnets.0.", top, top);
+    const std::string a = "decoder.mid_block.attentions.0.";
+    e.add(a + "group_norm.weight", {top}); e.add(a + "group_norm.bias", {top});
+    for (const char* n : {"to_q", "to_k", "to_v", "to_out.0"}) {
+        e.add(a + n + ".weight", {top, top});
+        e.add(a + n + ".bias", {top});
+    }
+    resnet("decoder.mid_block.resnets.1.", top, top);
+    int ch = top;
+    for (int i = 0; i < nl; ++i) {
+        const int co = c.block_out_channels[nl - 1 - i];
+        const std::string bp = "decoder.up_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            resnet(bp + "resnets." + std::to_string(j) + ".", ch, co);
+            ch = co;
+        }
+        if (i < nl - 1) {
+            e.add(bp + "upsamplers.0.conv.weight", {co, co, 3, 3});
+            e.add(bp + "upsamplers.0.conv.bias", {co});
+        }
+    }
+    e.add("decoder.conv_norm_out.weight", {ch}); e.add("decoder.conv_norm_out.bias", {ch});
+    e.add("decoder.conv_out.weight", {c.out_channels, ch, 3, 3});
+    e.add("decoder.conv_out.bias", {c.out_channels});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,7 +422,50 @@ void walk_blocks(const sd_unet_config& c, FR&& on_resnet, FT&& on_transformer) {
     }
 }
 
+int pack_vae(sd_unet* u) {
+    const sd_unet_config& c = u->cfg;
+    Packer pk{u};
+    const int nl = c.num_levels, top = c.block_out_channels[nl - 1];
+    pk.f32("post_quant_conv.weight"); pk.f32("post_quant_conv.bias");
+    {   // conv_in: [O][I][3][3] -> Wt[k = ic*9+tap][O] fp32
+        const auto& d = pk.P("decoder.conv_in.weight");
+        const int O = top, I = c.in_channels;
+        size_t off = pk.alloc("decoder.conv_in.weight", d.size() * 4);
+        float* o = (float*)(u->hblob.data() + off);
+        for (int oc = 0; oc < O; ++oc)
+            for (int k = 0; k < I * 9; ++k) o[(size_t)k * O + oc] = d[(size_t)oc * I * 9 + k];
+        pk.f32("decoder.conv_in.bias");
+    }
+    pk.resnet("decoder.mid_block.resnets.0.", top, top);
+    const std::string a = "decoder.mid_block.attentions.0.";
+    pk.f32(a + "group_norm.weight"); pk.f32(a + "group_norm.bias");
+    pk.concat_rows(a + "qk.weight", {a + "to_q.weight", a + "to_k.weight"});
+    {
+        size_t off = pk.alloc(a + "qk.bias", (size_t)2 * top * 4);
+        float* o = (float*)(u->hblob.data() + off);
+        for (const char* n : {"to_q.bias", "to_k.bias"})
+            for (float v : pk.P(a + n)) *o++ = v;
+    }
+    pk.bf16_same(a + "to_v.weight"); pk.f32(a + "to_v.bias");
+    pk.bf16_same(a + "to_out.0.weight"); pk.f32(a + "to_out.0.bias");
+    pk.resnet("decoder.mid_block.resnets.1.", top, top);
+    int ch = top;
+    for (int i = 0; i < nl; ++i) {
+        const int co = c.block_out_channels[nl - 1 - i];
+        const std::string bp = "decoder.up_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            pk.resnet(bp + "resnets." + std::to_string(j) + ".", ch, co);
+            ch = co;
+        }
+        if (i < nl - 1) { pk.conv3(bp + "upsamplers.0.conv.weight", co, co); pk.f32(bp + "upsamplers.0.conv.bias"); }
+    }
+    pk.f32("decoder.conv_norm_out.weight"); pk.f32("decoder.conv_norm_out.bias");
+    pk.conv3_ohwi("decoder.conv_out.weight", c.out_channels, ch); pk.f32("decoder.conv_out.bias");
+    return 0;
+}
+
 int pack_all(sd_unet* u) {
+    if (u->kind == 1) return pack_vae(u);
     const sd_unet_config& c = u->cfg;
     Packer pk{u};
     const int c0 = c.block_out_channels[0], temb = 4 * c0, nl = c.num_levels;
@@ -529,7 +621,83 @@ struct Builder {
         return gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
     }
 
+    // ---- AutoencoderKL decoder: latents/scale -> post_quant_conv -> decoder -> image ----
+    int vae_resnet(const std::string& p, int x, int cin, int cout, int res) {
+        const int hw = res * res, M = UB * hw;
+        int t1 = gn(x, cin, -1, 0, hw, p + "norm1.weight", p + "norm1.bias", 1e-6f, 1);
+        int t2 = conv3(t1, res, cin, cout, 1, 0, p + "conv1.weight", p + "conv1.bias", 0, -1, -1);
+        int t3 = gn(t2, cout, -1, 0, hw, p + "norm2.weight", p + "norm2.bias", 1e-6f, 1);
+        int sc = x;
+        if (cin != cout) sc = gemm(x, cin, -1, 0, M, cout, p + "conv_shortcut.weight", p + "conv_shortcut.bias", -1, 0);
+        return conv3(t3, res, cout, cout, 1, 0, p + "conv2.weight", p + "conv2.bias", 0, -1, sc);
+    }
+    // single-head attention with head dim C (512): too wide for the flash kernel's register tile, so it
+    // is three GEMMs per image (S = Q K^T, row softmax, O = P V with V^T produced directly by a GEMM)
+    int vae_attention(const std::string& p, int x, int C, int res) {
+        const int hw = res * res, M = UB * hw;
+        int g = gn(x, C, -1, 0, hw, p + "group_norm.weight", p + "group_norm.bias", 1e-6f, 0);
+        int qk = gemm(g, C, -1, 0, M, 2 * C, p + "qk.weight", p + "qk.bias", -1, 0);
+        const int vT = tensor((size_t)UB * C * hw * 2), S = tensor((size_t)hw * hw * 2), O = tensor((size_t)M * C * 2);
+        for (int img = 0; img < UB; ++img) {
+            {   // V^T[C, hw] = Wv[C, C] . g_img[hw, C]^T   (bias of V is added to O: rows of P sum to 1)
+                Op o; o.kind = OP_GEMM; o.wx = W(p + "to_v.weight"); o.ldx_o = C; o.K1 = C; o.K = C; o.M = C; o.N = hw;
+                o.wt = g; o.woff_el = (long)img * hw * C; o.ldw_o = C;
+                o.out = vT; o.coff = (long)img * C * hw; o.ldc_o = hw;
+                push(o);
+            }
+            {   // S[hw, hw] = Q_img . K_img^T
+                Op o; o.kind = OP_GEMM; o.x1 = qk; o.xoff = (long)img * hw * 2 * C; o.ldx_o = 2 * C; o.K1 = C; o.K = C;
+                o.M = hw; o.N = hw; o.wt = qk; o.woff_el = (long)img * hw * 2 * C + C; o.ldw_o = 2 * C;
+                o.out = S; o.ldc_o = hw;
+                push(o);
+            }
+            { Op o; o.kind = OP_SOFTMAX; o.x1 = S; o.out = S; o.M = hw; o.N = hw; o.scale = 1.0f / sqrtf((float)C); push(o); }
+            {   // O_img[hw, C] = P . V + b_v
+                Op o; o.kind = OP_GEMM; o.x1 = S; o.ldx_o = hw; o.K1 = hw; o.K = hw; o.M = hw; o.N = C;
+                o.wt = vT; o.woff_el = (long)img * C * hw; o.ldw_o = hw; o.b = W(p + "to_v.bias");
+                o.out = O; o.coff = (long)img * hw * C; o.ldc_o = C;
+                push(o);
+            }
+        }
+        return gemm(O, C, -1, 0, M, C, p + "to_out.0.weight", p + "to_out.0.bias", x, 0);
+    }
+    void build_vae() {
+        const sd_unet_config& c = u->cfg;
+        const int nl = c.num_levels, top = c.block_out_channels[nl - 1];
+        int res = c.sample_size;
+        int t_pq = tensor((size_t)UB * c.in_channels * res * res * 4);
+        { Op o; o.kind = OP_PQCONV; o.x1 = T_LATENTS; o.out = t_pq; o.B = UB; o.HW = res * res;
+          o.w = W("post_quant_conv.weight"); o.b = W("post_quant_conv.bias"); push(o); }
+        int h;
+        { Op o; o.kind = OP_CONV_IN; o.x1 = t_pq; o.B = UB; o.Hin = res; o.Win = res; o.Cin = c.in_channels; o.N = top;
+          o.w = W("decoder.conv_in.weight"); o.b = W("decoder.conv_in.bias"); o.out = tensor((size_t)UB * res * res * top * 2);
+          push(o); h = o.out; }
+        pl.taps["conv_in"] = h;
+        h = vae_resnet("decoder.mid_block.resnets.0.", h, top, top, res);
+        h = vae_attention("decoder.mid_block.attentions.0.", h, top, res);
+        h = vae_resnet("decoder.mid_block.resnets.1.", h, top, top, res);
+        pl.taps["mid"] = h;
+        int ch = top;
+        for (int i = 0; i < nl; ++i) {
+            const int co = c.block_out_channels[nl - 1 - i];
+            const std::string bp = "decoder.up_blocks." + std::to_string(i) + ".";
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                h = vae_resnet(bp + "resnets." + std::to_string(j) + ".", h, ch, co, res);
+                ch = co;
+            }
+            if (i < nl - 1) {
+                h = conv3(h, res, co, co, 1, 1, bp + "upsamplers.0.conv.weight", bp + "upsamplers.0.conv.bias", 0, -1, -1);
+                res *= 2;
+            }
+            pl.taps["up" + std::to_string(i)] = h;
+        }
+        int g = gn(h, ch, -1, 0, res * res, "decoder.conv_norm_out.weight", "decoder.conv_norm_out.bias", 1e-6f, 1);
+        { Op o; o.kind = OP_CONV_OUT; o.x1 = g; o.out = T_EPS; o.B = UB; o.Hin = res; o.Win = res; o.Cin = ch; o.N = c.out_channels;
+          o.w = W("decoder.conv_out.weight"); o.b = W("decoder.conv_out.bias"); push(o); }
+    }
+
     void build() {
+        if (u->kind == 1) { build_vae(); return; }
         const sd_unet_config& c = u->cfg;
         const int nl = c.num_levels, c0 = c.block_out_channels[0], temb = 4 * c0;
         const int L = c.context_len;
@@ -620,9 +788,9 @@ bool wrap_skipped(const Wrap& w, int branch) {
     return w.type == 0 ? w.layer_i >= cache_layer_id : w.layer_i > cache_layer_id;
 }
 
-void op_tensors(const Op& o, int ins[5], int& nin) {
+void op_tensors(const Op& o, int ins[6], int& nin) {
     nin = 0;
-    for (int t : {o.x1, o.x2, o.r, o.b2t})
+    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt})
         if (t >= 0) ins[nin++] = t;
 }
 
@@ -639,7 +807,7 @@ void assign_memory(sd_unet* u, Plan& pl) {
             if (pl.ops[i].out >= 0) producer[pl.ops[i].out] = i;
         for (int i = 0; i < nops; ++i) {
             if (pl.skipped[i]) continue;
-            int ins[5], nin;
+            int ins[6], nin;
             op_tensors(pl.ops[i], ins, nin);
             for (int k = 0; k < nin; ++k) {
                 const int p = producer[ins[k]];
@@ -652,7 +820,7 @@ void assign_memory(sd_unet* u, Plan& pl) {
     // lifetimes over the full plan
     for (int i = 0; i < nops; ++i) {
         const Op& o = pl.ops[i];
-        int ins[5], nin;
+        int ins[6], nin;
         op_tensors(o, ins, nin);
         for (int k = 0; k < nin; ++k) pl.tensors[ins[k]].last = std::max(pl.tensors[ins[k]].last, i);
         for (int t : {o.out, o.aux})
@@ -721,8 +889,14 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             return sd_launch_gemv((const float*)T(o.x1), (const bf16_t*)(wb + o.w), (const float*)(wb + o.b),
                                   (float*)T(o.out), o.N, o.K, o.silu_in, stream);
         case OP_CONV_IN:
-            return sd_launch_conv_in(latents, latent_batch, (const float*)(wb + o.w), (const float*)(wb + o.b),
-                                     (bf16_t*)T(o.out), o.B, o.Hin, o.Win, o.Cin, o.N, stream);
+            return sd_launch_conv_in(o.x1 >= 0 ? (const float*)T(o.x1) : latents, o.x1 >= 0 ? o.B : latent_batch,
+                                     (const float*)(wb + o.w), (const float*)(wb + o.b), (bf16_t*)T(o.out), o.B, o.Hin,
+                                     o.Win, o.Cin, o.N, stream);
+        case OP_PQCONV:
+            return sd_launch_pqconv(latents, (const float*)(wb + o.w), (const float*)(wb + o.b), (float*)T(o.out), o.B,
+                                    o.HW, timestep /* carries the latent scale for the VAE */, stream);
+        case OP_SOFTMAX:
+            return sd_launch_softmax_rows((bf16_t*)T(o.x1), o.M, o.N, o.scale, stream);
         case OP_GN: {
             GroupNormArgs a;
             a.x1 = (const bf16_t*)T(o.x1); a.C1 = o.C1; a.x2 = (const bf16_t*)T(o.x2); a.C2 = o.C2;
@@ -743,9 +917,12 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
         }
         case OP_GEMM: {
             GemmArgs a;
-            a.X = (const bf16_t*)T(o.x1); a.ldx = o.K1; a.X2 = (const bf16_t*)T(o.x2); a.ldx2 = o.K - o.K1; a.K1 = o.K1;
-            a.W = (const bf16_t*)(wb + o.w); a.bias = o.b != NOFF ? (const float*)(wb + o.b) : nullptr;
-            a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out); a.ldc = o.epi ? o.N / 2 : o.N;
+            a.X = o.wx != NOFF ? (const bf16_t*)(wb + o.wx) : (const bf16_t*)T(o.x1) + o.xoff;
+            a.ldx = o.ldx_o ? o.ldx_o : o.K1; a.X2 = (const bf16_t*)T(o.x2); a.ldx2 = o.K - o.K1; a.K1 = o.K1;
+            a.W = o.wt >= 0 ? (const bf16_t*)T(o.wt) + o.woff_el : (const bf16_t*)(wb + o.w); a.ldw = o.ldw_o;
+            a.bias = o.b != NOFF ? (const float*)(wb + o.b) : nullptr;
+            a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out) + o.coff;
+            a.ldc = o.ldc_o ? o.ldc_o : (o.epi ? o.N / 2 : o.N);
             a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
             return sd_launch_gemm(a, o.epi, stream);
         }
@@ -799,6 +976,43 @@ extern "C" int sd_unet_create(const sd_unet_config* cfg, sd_unet** out) {
     u->debug_taps = getenv("SD_DEBUG_TAPS") != nullptr;
     enumerate_params(u);
     *out = u;
+    return 0;
+}
+
+// ---- AutoencoderKL decoder: `self.vae.decode(latents / scaling_factor)` of src/models.py:287-302 ----
+extern "C" int sd_vae_create(const sd_unet_config* cfg, sd_unet** out) {
+    SD_REQUIRE(cfg && out, "sd_vae_create: null argument");
+    SD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8, "sd_vae_create: num_levels %d", cfg->num_levels);
+    SD_REQUIRE(cfg->in_channels == 4 && cfg->out_channels >= 1 && cfg->out_channels <= 4, "sd_vae_create: in/out channels");
+    for (int i = 0; i < cfg->num_levels; ++i) {
+        const int c = cfg->block_out_channels[i], cpg = cfg->norm_num_groups ? c / cfg->norm_num_groups : 0;
+        SD_REQUIRE(c % 64 == 0 && c % cfg->norm_num_groups == 0 && (cpg >= 8 || cpg == 4),
+                   "sd_vae_create: block_out_channels[%d]=%d must be a multiple of 64 with 4 or >= 8 channels per group", i, c);
+    }
+    SD_REQUIRE(cfg->sample_size >= 8 && cfg->sample_size <= 64 && (cfg->sample_size * cfg->sample_size) % 64 == 0,
+               "sd_vae_create: latent size %d (the mid-block attention handles 64 <= HW <= 4096 tokens)", cfg->sample_size);
+    sd_unet* u = new sd_unet();
+    u->kind = 1;
+    u->cfg = *cfg;
+    u->debug_taps = getenv("SD_DEBUG_TAPS") != nullptr;
+    enumerate_params_vae(u);
+    *out = u;
+    return 0;
+}
+
+extern "C" int sd_vae_decode(sd_unet* u, void* stream, const float* latents, int batch, float latent_scale,
+                             float* images_out, void* workspace, long long workspace_bytes) {
+    SD_REQUIRE(u && u->kind == 1, "vae_decode: not a VAE handle");
+    SD_REQUIRE(latents && images_out && workspace && batch > 0, "vae_decode: null argument");
+    Plan* pl;
+    int rc = get_plan(u, batch, -1, &pl);
+    if (rc) return rc;
+    SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "vae_decode: workspace too small (%lld < %zu)", workspace_bytes,
+               pl->total_bytes);
+    SD_REQUIRE(((uintptr_t)workspace & 255) == 0, "vae_decode: workspace must be 256-byte aligned");
+    for (size_t i = 0; i < pl->ops.size(); ++i)
+        if ((rc = run_op(u, *pl, pl->ops[i], (char*)workspace, latents, batch, images_out, latent_scale, (hipStream_t)stream)))
+            return rc;
     return 0;
 }
 
@@ -879,6 +1093,7 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
 extern "C" int sd_unet_forward(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
                                float timestep, float* eps_out, void* workspace, long long workspace_bytes,
                                int cache_mode, int cache_branch_id) {
+    SD_REQUIRE(u && u->kind == 0, "forward: not a UNet handle");
     SD_REQUIRE(latents && eps_out && workspace, "forward: null argument");
     SD_REQUIRE(latent_batch > 0 && unet_batch % latent_batch == 0, "forward: unet batch %d not a multiple of latent batch %d",
                unet_batch, latent_batch);

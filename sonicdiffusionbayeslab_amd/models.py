@@ -12,10 +12,10 @@ duplication is fused into conv_in, and CFG-combine + ``scheduler.step`` is one f
 Timing keeps the reference's definition -- wall-clock of the loop only (``:208,284-285``) -- but
 brackets it with device synchronisation so the number is real.
 
-Out of hot-path scope ("next" rows): the CLIP text encoder and the VAE decoder.
-Prompts are therefore encoded by a pluggable ``text_encoder`` (default: a deterministic seeded
-stand-in, since no CLIP weights exist offline) and ``output_type="latent"`` is the native
-output; ``"pt"`` needs a ``vae_decoder`` plugin.
+``output_type="pt"`` decodes through the libsdhip AutoencoderKL decoder (``vae.py``, SURVEY 8f row 1;
+outside the timed loop, as in the reference).  Still out of scope: the CLIP text
+encoder -- prompts are encoded by a pluggable ``text_encoder`` (default: a deterministic seeded
+stand-in, since no CLIP weights exist offline).
 """
 from __future__ import annotations
 
@@ -30,6 +30,7 @@ import torch
 from .registry import models_registry
 from .schedulers import PNDMConfigStub
 from .unet import CACHE_FULL_AND_STORE, CACHE_OFF, CACHE_SKIP, HipUNet2DConditionModel
+from .vae import HipVaeDecoder, VaeConfig, load_vae_state_dict, make_synthetic_vae_state_dict
 from .weights import UNetConfig, load_unet_state_dict, make_synthetic_state_dict
 
 
@@ -108,6 +109,21 @@ class StableDiffusionModel:
                 _fuse_synthetic_lora(sd, seed, scale, rank)
             self.unet = HipUNet2DConditionModel(self.unet_config, sd, device="cuda:%d" % torch.cuda.current_device())
             self._state_dict = None
+
+    def _ensure_vae(self):
+        """AutoencoderKL decoder on libsdhip; local weights if the model directory has
+        them, SD-1.5-shaped synthetic weights otherwise."""
+        if self.vae_decoder is None:
+            self._ensure_unet()
+            cfg = VaeConfig(sample_size=self.unet_config.sample_size)
+            path = os.environ.get("SD_AMD_MODEL_DIR", "")
+            try:
+                sd = load_vae_state_dict(path) if path and os.path.isdir(path) else None
+            except FileNotFoundError:
+                sd = None
+            sd = sd or make_synthetic_vae_state_dict(cfg)
+            self.vae_decoder = HipVaeDecoder(cfg, sd, device=str(self.unet.device))
+        return self.vae_decoder
 
     def to(self, device):
         """``model.to(device)`` (``base_experiment.py:64``; ``ddim.py:31,33``).  The UNet weights
@@ -245,14 +261,14 @@ class StableDiffusionModel:
         if output_type == "latent":
             image = latents
             image_x0 = x0_preds
+        elif output_type == "pt":
+            vae = self._ensure_vae()
+            inv = 1.0 / self.vae_config.scaling_factor
+            image = (vae.decode(latents, inv) / 2 + 0.5).clamp(0, 1)                               # :288,:312
+            # the reference decodes EVERY stored x0 prediction as well (:296-302)
+            image_x0 = [(vae.decode(x, inv) / 2 + 0.5).clamp(0, 1) for x in x0_preds]
         else:
-            if self.vae_decoder is None:
-                raise NotImplementedError(
-                    "VAE decode is a 'next' row outside the hot-path scope (SURVEY.md §8f.1): pass "
-                    "output_type='latent' or attach a vae_decoder plugin")
-            image = self.vae_decoder(latents / self.vae_config.scaling_factor)                    # :288
-            image = (image / 2 + 0.5).clamp(0, 1)                                                  # :312 postprocess("pt")
-            image_x0 = [(self.vae_decoder(x / self.vae_config.scaling_factor) / 2 + 0.5).clamp(0, 1) for x in x0_preds]
+            raise NotImplementedError(f"output_type {output_type!r}: 'latent' and 'pt' are built")
         if not return_dict:
             return (image, None), execution_time, image_x0
         return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0

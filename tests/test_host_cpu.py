@@ -102,6 +102,22 @@ def test_param_enumeration_matches_library():
     assert lib.sd_unet_create(C.byref(_c_config(bad)), C.byref(h)) != 0
 
 
+def test_vae_param_enumeration_matches_library():
+    from sonicdiffusionbayeslab_amd.vae import VaeConfig, _c_config, vae_param_shapes
+    lib = _lib.load()
+    cfg = VaeConfig()
+    h = C.c_void_p()
+    _lib.check(lib.sd_vae_create(C.byref(_c_config(cfg)), C.byref(h)))
+    shapes = vae_param_shapes(cfg)
+    assert lib.sd_unet_num_params(h) == len(shapes) == 140
+    assert sum(math.prod(s) for _, s in shapes) == 49490199          # SD-1.5 VAE decoder + post_quant_conv
+    name = C.create_string_buffer(256); shp = (C.c_longlong * 4)(); nd = C.c_int()
+    for i, (n, s) in enumerate(shapes):
+        _lib.check(lib.sd_unet_param_info(h, i, name, 256, shp, C.byref(nd)))
+        assert name.value.decode() == n and tuple(shp[: nd.value]) == tuple(s), (i, n)
+    lib.sd_unet_destroy(h)
+
+
 def test_product_fails_loudly_without_gpu():
     from sonicdiffusionbayeslab_amd.unet import HipUNet2DConditionModel
     if torch.cuda.is_available():

@@ -219,4 +219,4 @@ def test_prompt_strings_and_harness_call_shape(env):
                   num_inference_steps=2, guidance_scale=7.5, generator=g2, output_type="latent")[0]
     assert torch.equal(imgs.images, again.images)        # deterministic: same seed, same kernels
     with pytest.raises(NotImplementedError):
-        model(["x"], num_inference_steps=1, output_type="pt")   # VAE decode is a 'next' row
+        model(["x"], num_inference_steps=1, output_type="pil")
