@@ -280,6 +280,245 @@ __global__ __launch_bounds__(256, AttnCfg<D>::MIN_WAVES) void attn_kernel(const 
     }
 }
 
+
+// =====================================================================================================
+// LDS-DMA variant (D = 40, 80): K/V tiles go global -> LDS with 16-byte global_load_lds, no VGPR round
+// trip and no ds_write.  Ablation on MI355X showed the register-staged path spending 27 % of the
+// N = 4096 kernel in its staging (waiting for the one-tile-ahead loads, then ds_write_b128 issue);
+// the DMA ring is 3 tiles deep with a COUNTED vmcnt, so a tile has two iterations to land.
+// Row padding is produced by the per-lane SOURCE address (LDS stays lane-linear): pad chunks read a
+// zero page, and V's "ones column" (softmax denominator on the matrix core) reads a constant chunk.
+//   D = 40: K rows 80 B (5 chunks; the 3rd k-step over-reads 16 B of the next row, multiplied by the
+//           zero padding of Q), V rows 96 B (5 data + ones chunk)
+//   D = 80: K rows 176 B (10 data + zero chunk), V rows 192 B (10 data + ones chunk + zero chunk)
+// both conflict-free for the ds_read_b128 K fragments; 192 B is also conflict-free for the tr reads.
+// =====================================================================================================
+template <int D>
+struct DmaCfg {
+    static constexpr int DK = (D + 15) / 16 * 16, KQ = DK / 16, DVT = (D + 31) / 32, CD = D / 8;
+    static constexpr int CHK = D == 40 ? 5 : 11;
+    static constexpr int CHV = D == 40 ? 6 : 12;
+    static constexpr int RSK = CHK * 16, RSV = CHV * 16;
+    static constexpr int KBYTES = 64 * RSK, TILE = 64 * (RSK + RSV);
+    static constexpr int NI = CHK + CHV;               // 1-KiB DMA wave-instructions per tile
+    static constexpr int NW = 8;                       // waves per workgroup (32 queries each)
+    static constexpr int NIW = (NI + NW - 1) / NW;     // per wave (waves < NI % NW issue NIW, else NIW - 1)
+    static constexpr int NSLOT = 3;
+    static constexpr int SMEM = TILE * NSLOT + 256;    // tail pad: the last V row's tr reads run past its 96/192 B
+    static_assert(D == 40 || D == 80, "LDS-DMA attention is built for head dims 40 and 80");
+};
+
+template <int D>
+__global__ __launch_bounds__(DmaCfg<D>::NW * 64, D == 40 ? 4 : 3) void attn_dma_kernel(const AttnArgs a) {
+    using Cfg = DmaCfg<D>;
+    constexpr int KQ = Cfg::KQ, DVT = Cfg::DVT, CD = Cfg::CD, CHK = Cfg::CHK, CHV = Cfg::CHV;
+    constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, KBYTES = Cfg::KBYTES, TILE = Cfg::TILE, NI = Cfg::NI, NIW = Cfg::NIW;
+    constexpr int NW = Cfg::NW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q = blockIdx.x * (NW * 32) + wave * 32 + r;
+    const bool qvalid = q < a.Nq;
+    const float c = a.scale * 1.4426950408889634f;
+    const char* zero = (const char*)a.consts;
+    const char* ones = zero + 256;
+
+    bf16x8 qf[KQ];
+    {
+        const bf16_t* qp = a.Q + ((long)b * a.Nq + (qvalid ? q : 0)) * a.ldq + head * D;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int col = kk * 16 + h * 8;
+            if (qvalid && col < D) qf[kk] = *(const bf16x8*)(qp + col);
+            else qf[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(qf[kk]));   // retire the loads before the DMA ring starts
+    }
+
+    // ---- loop-invariant DMA descriptors: this wave issues instructions wave, wave+NW, ... < NI ----
+    const bf16_t* kbase = a.K + (long)b * a.Nk * a.ldk + head * D;
+    const bf16_t* vbase = a.V + (long)b * a.Nk * a.ldv + head * D;
+    int d_key[NIW], d_kind[NIW];        // kind: 0 K data, 1 V data, 2 zero pad, 3 ones chunk
+    long d_src[NIW];                    // element offset of the chunk inside a 64-key tile (data kinds)
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int inst = wave + NW * j;
+        d_key[j] = 0; d_kind[j] = 2; d_src[j] = 0;
+        if (inst < CHK) {
+            const int ch = inst * 64 + lane, key = ch / CHK, part = ch - key * CHK;
+            d_key[j] = key;
+            d_kind[j] = part < CD ? 0 : 2;
+            d_src[j] = (long)key * a.ldk + part * 8;
+        } else if (inst < NI) {
+            const int ch = (inst - CHK) * 64 + lane, key = ch / CHV, part = ch - key * CHV;
+            d_key[j] = key;
+            d_kind[j] = part < CD ? 1 : (part == CD ? 3 : 2);
+            d_src[j] = (long)key * a.ldv + part * 8;
+        }
+    }
+    auto issue = [&](int t, int slot) {
+        char* base = smem + slot * TILE;
+        const int k0 = t * 64;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int inst = wave + NW * j;
+            if (inst < NI) {                                    // wave-uniform
+                const bool live = k0 + d_key[j] < a.Nk;
+                const void* src = d_kind[j] == 3 ? (const void*)ones
+                                : (d_kind[j] == 2 || !live) ? (const void*)zero
+                                : d_kind[j] == 0 ? (const void*)(kbase + (long)k0 * a.ldk + d_src[j])
+                                                 : (const void*)(vbase + (long)k0 * a.ldv + d_src[j]);
+                // K instructions fill [0, KBYTES), V instructions follow; 1 KiB per instruction
+                glds16(src, base + inst * 1024);
+            }
+        }
+    };
+    static_assert(CHK * 1024 == KBYTES, "K region = CHK DMA instructions");
+
+    f32x16 o[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    float m_run = -1e30f;
+
+    const int kfrag_off = pi_swap23(r) * RSK + h * 16;
+    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int vtr_off = KBYTES + (8 * h + q4) * RSV + (16 * g16 + 4 * p4) * 2;
+
+    auto compute = [&](const char* tile, int key0) {
+        const bool two = key0 + 32 < a.Nk;
+        f32x16 s0, s1;
+        {
+            const char* kp = tile + kfrag_off;
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp), qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+            for (int kk = 1; kk < KQ; ++kk)
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + kk * 32), qf[kk], s0, 0, 0, 0);
+            if (two) {
+                kp += 32 * RSK;
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp), qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+                for (int kk = 1; kk < KQ; ++kk)
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + kk * 32), qf[kk], s1, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s1[i] = -1e30f;
+            }
+        }
+        if (key0 + 64 > a.Nk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kr = pi_swap23((i & 3) + 8 * (i >> 2) + 4 * h);
+                if (key0 + kr >= a.Nk) s0[i] = -1e30f;
+                if (key0 + 32 + kr >= a.Nk) s1[i] = -1e30f;
+            }
+        }
+        float tmax = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(s0[i], s1[i]));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tmax),
+                                                             __builtin_bit_cast(unsigned, tmax), false, false);
+            tmax = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        const float m_new = fmaxf(m_run, tmax);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int tt = 0; tt < DVT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[tt][i] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sv = s2 < 2 ? s0[8 * s2 + j] : s1[8 * (s2 - 2) + j];
+                p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -mc));
+            }
+            u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+            pf[s2] = __builtin_bit_cast(bf16x8, w);
+        }
+#pragma unroll
+        for (int tt = 0; tt < DVT; ++tt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                if (s2 >= 2 && !two) break;
+                const char* ap = tile + s2 * 16 * RSV + vtr_off + tt * 64;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(ap));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(ap + 4 * RSV));
+                const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[tt], 0, 0, 0);
+            }
+        }
+    };
+
+    const int ntiles = (a.Nk + 63) / 64;
+    const bool more = (NI % NW == 0) || (wave < NI % NW);   // this wave issues NIW (else NIW - 1) per tile
+    issue(0, 0);
+    if (ntiles > 1) issue(1, 1);
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {               // leave tile t+1 in flight
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();       // tile t landed for every wave; tile t-1 fully consumed
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue(t + 2, slot == 0 ? 2 : slot - 1);    // ring slot of tile t-1
+        compute(smem + slot * TILE, t * 64);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+    // row D of O^T holds sum(P) (ones chunk): tile D/32, row D%32 -> register (RR&3) + 4*(RR>>3), h = 0 half
+    constexpr int TT = D / 32, RR = D % 32, REG = (RR & 3) + 4 * (RR >> 3);
+    static_assert((RR & 4) == 0, "ones row must sit in the h = 0 half");
+    const float inv = 1.0f / __shfl(o[TT][REG], r);
+    if (qvalid) {
+        bf16_t* op = a.O + ((long)b * a.Nq + q) * a.ldo + head * D;
+#pragma unroll
+        for (int tt = 0; tt < DVT; ++tt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dv = 32 * tt + 8 * g4 + 4 * h;
+                if (dv < D) {
+                    u32x2 w = {pack2bf(o[tt][4 * g4 + 0] * inv, o[tt][4 * g4 + 1] * inv),
+                               pack2bf(o[tt][4 * g4 + 2] * inv, o[tt][4 * g4 + 3] * inv)};
+                    *(u32x2*)(op + dv) = w;
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_attn_dma(const AttnArgs& a, hipStream_t stream) {
+    // SD_ATTN_LDS_PAD (KiB): occupancy experiment knob -- extra dynamic LDS limits workgroups per CU
+    static const int pad = getenv("SD_ATTN_LDS_PAD") ? atoi(getenv("SD_ATTN_LDS_PAD")) * 1024 : 0;
+    const int smem = DmaCfg<D>::SMEM + pad;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_dma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    constexpr int QB = DmaCfg<D>::NW * 32;
+    dim3 grid((a.Nq + QB - 1) / QB, a.heads, a.B);
+    hipLaunchKernelGGL((attn_dma_kernel<D>), grid, dim3(DmaCfg<D>::NW * 64), smem, stream, a);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
     const int smem = AttnCfg<D>::SMEM;
@@ -309,9 +548,11 @@ int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
     SD_REQUIRE(((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V) % 16 == 0 && (uintptr_t)a.O % 8 == 0,
                "attention: operands must be 16-byte aligned");
     SD_REQUIRE(a.B <= 65535 && a.heads <= 65535, "attention: grid too large");
+    static const bool no_dma = getenv("SD_ATTN_NO_DMA") != nullptr;
+    const bool dma = !no_dma && a.consts != nullptr;
     switch (a.D) {
-        case 40: return launch_attn<40>(a, stream);
-        case 80: return launch_attn<80>(a, stream);
+        case 40: return dma ? launch_attn_dma<40>(a, stream) : launch_attn<40>(a, stream);
+        case 80: return dma ? launch_attn_dma<80>(a, stream) : launch_attn<80>(a, stream);
         case 160: return launch_attn<160>(a, stream);
         default: sd_set_error("attention: head dim %d not supported (40, 80, 160)", a.D); return -1;
     }

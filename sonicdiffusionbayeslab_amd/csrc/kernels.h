@@ -64,6 +64,7 @@ struct AttnArgs {
     bf16_t* O = nullptr; long ldo = 0;
     int B = 0, heads = 0, Nq = 0, Nk = 0, D = 0;
     float scale = 0.f;
+    const void* consts = nullptr;   // device page: 16 zero bytes at +0, the bf16 chunk {1,0,0,0,0,0,0,0} at +256
 };
 int sd_launch_attention(const AttnArgs& a, hipStream_t stream);
 

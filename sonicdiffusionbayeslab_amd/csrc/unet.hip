@@ -52,6 +52,8 @@ static int ensure_zero_page() {
     if (g_zero_page) return 0;
     SD_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
     SD_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+    const unsigned short one_chunk[8] = {0x3F80, 0, 0, 0, 0, 0, 0, 0};   // bf16 1.0 then zeros (attention ones column)
+    SD_CHECK_HIP(hipMemcpy((char*)g_zero_page + 256, one_chunk, sizeof(one_chunk), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -937,6 +939,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.O = (bf16_t*)T(o.out); a.ldo = o.ldo;
             a.B = o.B; a.heads = o.heads; a.Nq = o.Nq; a.Nk = o.Nk; a.D = o.D;
             a.scale = 1.0f / sqrtf((float)o.D);
+            a.consts = g_zero_page;
             return sd_launch_attention(a, stream);
         }
         case OP_CONV_OUT:
@@ -1260,6 +1263,8 @@ extern "C" int sd_op_attention(void* stream, const void* Q, long long ldq, const
     AttnArgs a;
     a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
     a.O = (bf16_t*)O; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
+    if (ensure_zero_page()) return -2;
+    a.consts = g_zero_page;
     return sd_launch_attention(a, (hipStream_t)stream);
 }
 
