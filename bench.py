@@ -75,6 +75,19 @@ def cpu_baseline(cfg, sd, args):
                       f"PyTorch-CPU oracle) in {dt:.1f}s, extrapolated to {args.ddim_steps} steps"}
 
 
+def conv_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/run_traffic.sh ->
+    profiles/round1_conv_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the 50 conv launches of
+    one forward at this bench shape).  PMC counters cannot be read live inside this process, so the number is
+    the profile's; None if the file is absent."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_conv_traffic.json")
+    try:
+        with open(p) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     from sonicdiffusionbayeslab_amd import dist as sdist
@@ -165,7 +178,7 @@ def main():
         ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<128,160,2,2,CONV,STD> (implicit-GEMM 3x3 conv)",
                            "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                           "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": conv_traffic_bytes(),
                            "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
                            "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
         tot = sum(v["ms"] for v in prof.values())
