@@ -1,0 +1,334 @@
+// 3x3 stride-1 convolution with an LDS-resident input halo (gfx950).
+//
+// The implicit-GEMM kernel of gemm_conv.hip stages the shifted input pixels of every tap again:
+// per 64-channel slice 9 x (128 x 128 B) of X next to 9 x (160 x 128 B) of W, and its LDS fill
+// (16-B `global_load_lds`, ~64 B/clk/CU) is as long as the MFMA work of the tile.  Here one
+// workgroup owns 256 consecutive output pixels (whole image rows) x 160 output channels and
+// keeps the input HALO of those pixels -- (rows + 2) x (width + 2) pixel slots of 128 B -- in
+// LDS for a whole channel slice; the nine taps read it at shifted addresses.  Per slice that is
+// <= 56 KiB of X once plus 9 x 20 KiB of W for 256 rows: 2.8x fewer fill bytes per flop.
+//
+//   LDS: 2 halo buffers (slice s / s+1) x 448 slots x 128 B + 2 W stages x 160 rows x 128 B = 152 KiB,
+//        one workgroup of 8 waves (4 along pixels x 2 along channels) per CU.
+//   Slots and W rows hold their eight 16-B chunks XOR-swizzled by (slot & 7) / (row & 7), applied to
+//   the per-lane SOURCE address of the LDS-DMA; a fragment read of 16 consecutive pixels is then
+//   bank-conflict free for every tap shift.
+//   K order = (slice, tap, channel), weights packed [Cout][Cin/64][9][64] as for the implicit GEMM.
+//   Zero padding and M/N tails read the zero page.
+//   Split-K runs over channel slices (fp32 slabs + splitk_reduce_kernel of gemm_conv.hip).
+#include "common.h"
+#include "kernels.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 256, BN = 160;
+constexpr int TM = 4, TN = 5;                 // 16x16 tiles per wave: 64 pixels x 80 channels
+constexpr int WTM = 64, WTN = 80;
+constexpr int HSLOTS = 448;                   // 7 DMA pieces of 64 slots
+constexpr int HPIECES = HSLOTS * 8 / 512;
+constexpr int HBYTES = HSLOTS * 128;
+constexpr int WBYTES = BN * 128;
+constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage
+constexpr int SMEM = 2 * HBYTES + 2 * WBYTES;
+static_assert(SMEM <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
+constexpr unsigned NOSRC = 0xffffffffu;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware order: workgroups of one XCD (blockIdx % 8) take consecutive items, n fastest, so the
+    // n-tiles that share an input halo read it from the same L2.
+    int work = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = work & 7, idx = work >> 3;
+        work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int split = work / ntiles;
+    const int t = work - split * ntiles;
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int S = p.Cin >> 6;
+    const int s_begin = (int)((long)S * split / p.splitk), s_end = (int)((long)S * (split + 1) / p.splitk);
+
+    // tile geometry: npiece pieces of RW whole rows (npiece > 1 only when an image has < 256 pixels)
+    const int H = p.Hin, W = p.Win, HW = H * W;
+    const int RW = min(H, BM / W);
+    const int PW = W + 2, PP = (RW + 2) * PW;
+    const int PIX = RW * W;                      // pixels per piece
+    const int HP = (BM / PIX) * PP;              // halo slots in use (<= HSLOTS, checked on the host)
+
+    const char* zero = (const char*)p.zero_page;
+    const char* Xb = (const char*)p.X;
+    const char* Wg = (const char*)p.W;
+
+    // ---- LDS-DMA source descriptors (byte offsets; NOSRC = zero page) ------------------------------
+    unsigned hoff[HPIECES];
+#pragma unroll
+    for (int j = 0; j < HPIECES; ++j) {
+        const int L = j * 512 + tid;
+        const int slot = L >> 3, cpos = L & 7;
+        unsigned off = NOSRC;
+        if (slot < HP) {
+            const int i = slot / PP, rem = slot - i * PP;
+            const int hy = rem / PW, hx = rem - hy * PW;
+            const int mp = m0 + i * PIX;
+            const int b = mp / HW, y0 = (mp - b * HW) / W;
+            const int y = y0 + hy - 1, x = hx - 1;
+            if (mp < p.M && y >= 0 && y < H && x >= 0 && x < W)
+                off = (unsigned)((((long)b * H + y) * W + x) * p.Cin * 2 + ((cpos ^ (slot & 7)) << 4));
+        }
+        hoff[j] = off;
+    }
+    unsigned woffs[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pc = wave + i * 8;
+        const int n = n0 + pc * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (lane >> 3);
+        woffs[i] = (pc < WPIECES && n < p.N) ? (unsigned)((long)n * p.ldw * 2 + (c << 4)) : NOSRC;
+    }
+    auto issue_h = [&](int j, int s, char* hb) {
+        const void* src = hoff[j] != NOSRC ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
+        glds16(src, hb + j * 8192 + wave * 1024);
+    };
+    auto issue_w = [&](int kk, char* wb) {       // kk = slice * 9 + tap
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pc = wave + i * 8;
+            if (pc < WPIECES) {                  // wave-uniform
+                const void* src = woffs[i] != NOSRC ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
+                glds16(src, wb + pc * 1024);
+            }
+        }
+    };
+
+    // ---- fragment addressing --------------------------------------------------------------------
+    const int wm = wave & 3, wn = wave >> 2;
+    const int lrow = lane & 15, lq = lane >> 4;
+    int hpc[TM];                                  // halo slot of this lane's pixel (tap centre)
+#pragma unroll
+    for (int f = 0; f < TM; ++f) {
+        const int pt = wm * WTM + f * 16 + lrow;
+        const int i = pt / PIX, rem = pt - i * PIX;
+        const int r = rem / W, col = rem - r * W;
+        hpc[f] = i * PP + (r + 1) * PW + col + 1;
+    }
+    const int wfrag = (wn * WTN + lrow) * 128;
+    const int wswz0 = (lq ^ (lane & 7)) << 4;     // k-step 1 = ^ 64
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    };
+
+    char* const Hb0 = smem;
+    char* const Hb1 = smem + HBYTES;
+    char* const Wb0 = smem + 2 * HBYTES;
+    char* const Wb1 = Wb0 + WBYTES;
+
+    // prologue: halo of the first slice + first W stage
+#pragma unroll
+    for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, Hb0);
+    issue_w(s_begin * 9, Wb0);
+
+    int wsel = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const bool odd = (s - s_begin) & 1;
+        const char* hcur = odd ? Hb1 : Hb0;
+        char* hnext = odd ? Hb0 : Hb1;
+        const bool more = s + 1 < s_end;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // everything issued one K tile ago has landed; every wave is done reading the buffers that
+            // are refilled below (W stage of tile kt-1, halo of slice s-1)
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* wcur = wsel ? Wb1 : Wb0;
+            char* wnext = wsel ? Wb0 : Wb1;
+            const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
+            int xa[TM];
+#pragma unroll
+            for (int f = 0; f < TM; ++f) {
+                const int hp = hpc[f] + toff;
+                xa[f] = hp * 128 + ((lq ^ (hp & 7)) << 4);
+                xf0[f] = *(const bf16x8*)(hcur + xa[f]);
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap < HPIECES && more) issue_h(tap, s + 1, hnext);
+            if (tap < 8) issue_w(s * 9 + tap + 1, wnext);
+            else if (more) issue_w((s + 1) * 9, wnext);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
+            mfmas(xf0, wf0);
+            mfmas(xf1, wf1);
+            wsel ^= 1;
+        }
+    }
+
+    // ---- epilogue (accumulator layout as gemm_kernel: lane owns 4 consecutive channels of one pixel) --
+    if (p.splitk > 1) {
+        float* slab = p.slab + (long)split * p.M * p.N;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wn * WTN + a * 16 + lq * 4;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * WTM + b * 16 + lrow;
+                if (m >= p.M) continue;
+                *(f32x4*)(slab + (long)m * p.N + n) = acc[a][b];
+            }
+        }
+        return;
+    }
+    if (p.R) {
+        u32x2 rr[TN][TM];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = min(n0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = min(m0 + wm * WTM + b * 16 + lrow, p.M - 1);
+                rr[a][b] = *(const u32x2*)(p.R + (long)m * p.ldr + n);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                acc[a][b][0] += bflo(rr[a][b][0]); acc[a][b][1] += bfhi(rr[a][b][0]);
+                acc[a][b][2] += bflo(rr[a][b][1]); acc[a][b][3] += bfhi(rr[a][b][1]);
+            }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = min(n0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+            f32x4 bv = *(const f32x4*)(p.bias + n);
+            if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] += bv;
+        }
+    }
+    // v_permlane16_swap pairs two adjacent 16-channel tiles: 16 contiguous bytes per lane and store
+    const bool wide_ok = (p.ldc & 7) == 0;
+    auto store_narrow = [&](int a) {
+        const int n = n0 + wn * WTN + a * 16 + lq * 4;
+        if (n >= p.N) return;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = m0 + wm * WTM + b * 16 + lrow;
+            const f32x4 v = acc[a][b];
+            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            if (m < p.M) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < TN; a += 2) {
+        const int nb = n0 + wn * WTN + a * 16;
+        if (a + 1 < TN && wide_ok && nb + 32 <= p.N) {
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * WTM + b * 16 + lrow;
+                const f32x4 vx = acc[a][b], vy = acc[a + 1 < TN ? a + 1 : a][b];
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
+                if (m < p.M) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+            }
+        } else {
+            store_narrow(a);
+            if (a + 1 < TN) store_narrow(a + 1);
+        }
+    }
+}
+
+bool halo_enabled() {
+    static const char* env = getenv("SD_CONV_HALO");
+    return env ? atoi(env) != 0 : true;
+}
+
+}  // namespace
+
+// The halo kernel takes stride-1, un-upsampled convs whose 256-pixel tiles are whole image rows and whose
+// halo fits the 448 slots (SD-1.5: the 64x64, 32x32 and 16x16 levels).  Everything else stays on the
+// implicit-GEMM kernel.
+bool sd_conv_halo_applicable(const GemmArgs& a) {
+    if (!halo_enabled() || a.stride != 1 || a.up) return false;
+    const int H = a.Hin, W = a.Win;
+    if (W < 16 || W > BM || BM % W) return false;
+    const int RW = H < BM / W ? H : BM / W;
+    const int PIX = RW * W;
+    if (BM % PIX || (H * W) % PIX) return false;
+    if ((BM / PIX) * (RW + 2) * (W + 2) > HSLOTS) return false;
+    if ((long)a.M * a.Cin * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
+    return true;
+}
+
+// Split-K over channel slices: one 8-wave workgroup per CU, so aim at >= 256 work items.
+int sd_conv_halo_splitk(int M, int N, int Cin) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (tiles >= 192) return 1;
+    const int S = Cin / 64;
+    int want = (256 + tiles - 1) / tiles;
+    int maxs = S / 4;                            // >= 4 slices (36 K tiles) per split
+    int s = want < maxs ? want : maxs;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : s;
+}
+
+// Split factor for a 3x3 conv, whichever kernel will run it (the plan sizes the slab with this).
+int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up) {
+    static const char* env = getenv("SD_SPLITK");
+    GemmArgs a;
+    a.M = M; a.N = N; a.Cin = Cin; a.K = 9 * Cin; a.ldw = a.K; a.Hin = Hin; a.Win = Win; a.stride = stride; a.up = up;
+    if (!env && sd_conv_halo_applicable(a)) return sd_conv_halo_splitk(M, N, Cin);
+    return sd_gemm_splitk(M, N, 9 * Cin);
+}
+
+int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    if (a.ldw == 0) a.ldw = a.K;
+    if (a.slab == nullptr || a.splitk < 1) a.splitk = 1;
+    SD_REQUIRE(a.splitk <= a.Cin / 64, "conv3x3 halo: splitk %d exceeds the %d channel slices", a.splitk, a.Cin / 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int grid = a.tiles_m * a.tiles_n * a.splitk;
+    hipLaunchKernelGGL(conv_halo_kernel, dim3(grid), dim3(512), SMEM, stream, a);
+    if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}

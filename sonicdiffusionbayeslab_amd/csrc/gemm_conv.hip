@@ -460,15 +460,17 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     int grid = a.tiles_m * a.tiles_n * a.splitk;
     if (STAGES == 2 && grid > kPersistentGrid) grid = kPersistentGrid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, stream, a);
-    if (a.splitk > 1) {
-        const long n4 = (long)a.M * (a.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a);
-    }
+    if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
+
+void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
+    const long n4 = (long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a);
+}
 
 // The 256-row, 8-wave, 3-stage (counted-vmcnt) tile, one workgroup per CU.  Measured on MI355X at
 // the SD-1.5 shapes it ties or loses to two independent 128-row workgroups per CU (its 8 waves
@@ -523,6 +525,7 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
                "conv3x3: output size %dx%d inconsistent with input %dx%d stride %d up %d", a.Hout, a.Wout,
                a.Hin, a.Win, a.stride, a.up);
     SD_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "conv3x3: M not a multiple of Hout*Wout");
+    if (sd_conv_halo_applicable(a)) return sd_launch_conv3x3_halo(a, stream);
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_CONV, EPI_STD>(a, stream);
     return launch<128, 160, 2, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
 }

@@ -32,6 +32,11 @@ struct GemmArgs {
 int sd_gemm_splitk(int M, int N, int K);   // heuristic split factor (1 = none) for the std epilogue
 int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu*/, hipStream_t stream);
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
+void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // slab -> C (+bias +bias2 +R)
+// conv_halo.hip: LDS-resident-halo kernel for stride-1 convs on whole-row tiles
+bool sd_conv_halo_applicable(const GemmArgs& a);
+int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up);
+int sd_launch_conv3x3_halo(const GemmArgs& a, hipStream_t stream);
 
 // GroupNorm over NHWC (optionally a two-tensor channel concat) -> bf16 [B, HW, C1+C2]
 struct GroupNormArgs {

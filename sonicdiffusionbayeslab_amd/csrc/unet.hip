@@ -559,7 +559,7 @@ struct Builder {
         o.Hout = o.Wout = (hv + 2 - 3) / stride + 1;
         o.M = UB * o.Hout * o.Wout; o.K = 9 * cin;
         o.w = W(w); o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
-        o.splitk = sd_gemm_splitk(o.M, o.N, o.K);
+        o.splitk = sd_conv3x3_splitk(o.M, o.N, cin, hin, hin, stride, up);
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * o.M * o.N * 4);
         o.out = tensor((size_t)o.M * cout * 2);
         push(o);
@@ -1234,7 +1234,7 @@ extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const f
     a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = stride; a.up = upsample ? 1 : 0;
     a.Hout = ((Hin << a.up) + 2 - 3) / stride + 1; a.Wout = ((Win << a.up) + 2 - 3) / stride + 1;
     a.M = B * a.Hout * a.Wout; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page;
-    a.splitk = sd_gemm_splitk(a.M, a.N, a.K);
+    a.splitk = sd_conv3x3_splitk(a.M, a.N, Cin, Hin, Win, stride, a.up);
     if (a.splitk > 1) {
         a.slab = (float*)op_scratch((size_t)a.splitk * a.M * a.N * 4);
         SD_REQUIRE(a.slab, "sd_op_conv3x3: cannot allocate split-K scratch");

@@ -113,6 +113,10 @@ def test_gemm_geglu(sdlib):
     (2, 16, 320, 320, 2, 0, False),
     (2, 8, 320, 640, 1, 1, False),
     (3, 6, 64, 64, 1, 0, True),      # M tail (108 rows), single K tile per tap
+    (1, 64, 128, 320, 1, 0, True),   # LDS-halo kernel: 4 rows of 64 pixels per tile
+    (2, 32, 192, 128, 1, 0, False),  # halo kernel, Cout tail inside the only channel tile
+    (3, 16, 320, 192, 1, 0, True),   # halo kernel, one image per tile, partial second channel tile
+    (1, 16, 1280, 320, 1, 0, True),  # halo kernel with split-K over channel slices
 ])
 def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
     g = torch.Generator().manual_seed(B * 100 + H + Cin)
