@@ -61,11 +61,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     const int S = p.Cin >> 6;
     const int s_begin = (int)((long)S * split / p.splitk), s_end = (int)((long)S * (split + 1) / p.splitk);
 
-    // tile geometry: npiece pieces of RW whole rows (npiece > 1 only when an image has < 256 pixels)
-    const int H = p.Hin, W = p.Win, HW = H * W;
-    const int RW = min(H, BM / W);
-    const int PW = W + 2, PP = (RW + 2) * PW;
-    const int PIX = RW * W;                      // pixels per piece
+    // tile geometry: BM / PIX pieces of RW whole OUTPUT rows (more than one piece only when an image has
+    // fewer than 256 pixels).  With the fused nearest-2x upsample (p.up = 1) the halo lives in the
+    // low-resolution input: (RW / 2 + 2) x (Win + 2) slots, and a tap reads slot ((y + dy - 1) >> 1, ...).
+    const int up = p.up;
+    const int Ho = p.Hout, Wo = p.Wout, HWo = Ho * Wo;
+    const int RW = min(Ho, BM / Wo);
+    const int PW = p.Win + 2, PP = ((RW >> up) + 2) * PW;
+    const int PIX = RW * Wo;                     // output pixels per piece
     const int HP = (BM / PIX) * PP;              // halo slots in use (<= HSLOTS, checked on the host)
 
     const char* zero = (const char*)p.zero_page;
@@ -83,10 +86,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             const int i = slot / PP, rem = slot - i * PP;
             const int hy = rem / PW, hx = rem - hy * PW;
             const int mp = m0 + i * PIX;
-            const int b = mp / HW, y0 = (mp - b * HW) / W;
-            const int y = y0 + hy - 1, x = hx - 1;
-            if (mp < p.M && y >= 0 && y < H && x >= 0 && x < W)
-                off = (unsigned)((((long)b * H + y) * W + x) * p.Cin * 2 + ((cpos ^ (slot & 7)) << 4));
+            const int b = mp / HWo, oy0 = (mp - b * HWo) / Wo;
+            const int y = (oy0 >> up) + hy - 1, x = hx - 1;
+            if (mp < p.M && y >= 0 && y < p.Hin && x >= 0 && x < p.Win)
+                off = (unsigned)((((long)b * p.Hin + y) * p.Win + x) * p.Cin * 2 + ((cpos ^ (slot & 7)) << 4));
         }
         hoff[j] = off;
     }
@@ -116,13 +119,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     // ---- fragment addressing --------------------------------------------------------------------
     const int wm = wave & 3, wn = wave >> 2;
     const int lrow = lane & 15, lq = lane >> 4;
-    int hpc[TM];                                  // halo slot of this lane's pixel (tap centre)
+    int hbase[TM], hrow[TM], hcol[TM];            // this lane's pixels: piece base slot (+1,+1), row, column
 #pragma unroll
     for (int f = 0; f < TM; ++f) {
         const int pt = wm * WTM + f * 16 + lrow;
         const int i = pt / PIX, rem = pt - i * PIX;
-        const int r = rem / W, col = rem - r * W;
-        hpc[f] = i * PP + (r + 1) * PW + col + 1;
+        hrow[f] = rem / Wo;
+        hcol[f] = rem - hrow[f] * Wo;
+        hbase[f] = i * PP + PW + 1;
     }
     const int wfrag = (wn * WTN + lrow) * 128;
     const int wswz0 = (lq ^ (lane & 7)) << 4;     // k-step 1 = ^ 64
@@ -167,11 +171,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             asm volatile("" ::: "memory");
             const char* wcur = wsel ? Wb1 : Wb0;
             char* wnext = wsel ? Wb0 : Wb1;
-            const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
             int xa[TM];
 #pragma unroll
             for (int f = 0; f < TM; ++f) {
-                const int hp = hpc[f] + toff;
+                const int hp = hbase[f] + ((hrow[f] + (tap / 3 - 1)) >> up) * PW + ((hcol[f] + (tap % 3 - 1)) >> up);
                 xa[f] = hp * 128 + ((lq ^ (hp & 7)) << 4);
                 xf0[f] = *(const bf16x8*)(hcur + xa[f]);
             }
@@ -278,17 +281,18 @@ bool halo_enabled() {
 
 }  // namespace
 
-// The halo kernel takes stride-1, un-upsampled convs whose 256-pixel tiles are whole image rows and whose
-// halo fits the 448 slots (SD-1.5: the 64x64, 32x32 and 16x16 levels).  Everything else stays on the
-// implicit-GEMM kernel.
+// The halo kernel takes stride-1 convs (optionally with the fused nearest-2x upsample) whose 256-pixel tiles
+// are whole output rows and whose halo fits the 448 slots: every stride-1 conv of the SD-1.5 UNet.  Strided
+// convs and wide images (the VAE decoder) stay on the implicit-GEMM kernel.  At width 8 a 16-pixel fragment
+// spans two rows and its LDS read is 2-way bank conflicted on a few lanes; it still beats re-staging X.
 bool sd_conv_halo_applicable(const GemmArgs& a) {
-    if (!halo_enabled() || a.stride != 1 || a.up) return false;
-    const int H = a.Hin, W = a.Win;
-    if (W < 16 || W > BM || BM % W) return false;
+    if (!halo_enabled() || a.stride != 1) return false;
+    const int H = a.Hin << a.up, W = a.Win << a.up;          // output = upsampled input size
+    if (W < 8 || W > BM || BM % W) return false;
     const int RW = H < BM / W ? H : BM / W;
     const int PIX = RW * W;
-    if (BM % PIX || (H * W) % PIX) return false;
-    if ((BM / PIX) * (RW + 2) * (W + 2) > HSLOTS) return false;
+    if (BM % PIX || (H * W) % PIX || (a.up && (RW & 1))) return false;
+    if ((BM / PIX) * ((RW >> a.up) + 2) * (a.Win + 2) > HSLOTS) return false;
     if ((long)a.M * a.Cin * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
     return true;
 }
@@ -299,7 +303,7 @@ int sd_conv_halo_splitk(int M, int N, int Cin) {
     if (tiles >= 192) return 1;
     const int S = Cin / 64;
     int want = (256 + tiles - 1) / tiles;
-    int maxs = S / 4;                            // >= 4 slices (36 K tiles) per split
+    int maxs = tiles < 64 ? S / 2 : S / 4;       // >= 4 slices (36 K tiles) per split; >= 2 on tiny grids
     int s = want < maxs ? want : maxs;
     if (s > 8) s = 8;
     return s < 1 ? 1 : s;

@@ -458,7 +458,8 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
         attr_set = true;
     }
     int grid = a.tiles_m * a.tiles_n * a.splitk;
-    if (STAGES == 2 && grid > kPersistentGrid) grid = kPersistentGrid;
+    constexpr int persistent = smem > 80 * 1024 ? kPersistentGrid / 2 : kPersistentGrid;   // workgroups that fit a CU
+    if (STAGES == 2 && grid > persistent) grid = persistent;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, stream, a);
     if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
@@ -475,11 +476,13 @@ void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
 // The 256-row, 8-wave, 3-stage (counted-vmcnt) tile, one workgroup per CU.  Measured on MI355X at
 // the SD-1.5 shapes it ties or loses to two independent 128-row workgroups per CU (its 8 waves
 // issue their LDS-DMA in lockstep after the barrier), so it is opt-in: SD_GEMM_BIG=1.
-static bool big_tile_ok(int M, int N, int BN) {
+static int big_tile_mode() {
     static const char* env = getenv("SD_GEMM_BIG");
-    if (env) return atoi(env) != 0;
+    return env ? atoi(env) : 0;
+}
+static bool big_tile_ok(int M, int N, int BN) {
     (void)M; (void)N; (void)BN;
-    return false;
+    return big_tile_mode() == 1;
 }
 
 // Split-K factor for a (M, N, K) problem on the 128x160 tile: only when the tile grid cannot fill
@@ -507,9 +510,11 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     if (epi == EPI_GEGLU) {
         SD_REQUIRE(a.N % 32 == 0, "geglu gemm: N=%d must be a multiple of 32", a.N);
         if (big_tile_ok(a.M, a.N, 128)) return launch<256, 128, 4, 2, 3, AMODE_GEMM, EPI_GEGLU>(a, stream);
+        if (big_tile_mode() == 2 && a.N % 256 == 0) return launch<256, 256, 4, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
         return launch<128, 128, 2, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
     }
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
+    if (big_tile_mode() == 2) return launch<256, 160, 4, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
     return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
 }
 

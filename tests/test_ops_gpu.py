@@ -117,6 +117,10 @@ def test_gemm_geglu(sdlib):
     (2, 32, 192, 128, 1, 0, False),  # halo kernel, Cout tail inside the only channel tile
     (3, 16, 320, 192, 1, 0, True),   # halo kernel, one image per tile, partial second channel tile
     (1, 16, 1280, 320, 1, 0, True),  # halo kernel with split-K over channel slices
+    (2, 16, 128, 320, 1, 1, True),   # halo kernel, fused upsample to 32x32 (8 output rows per tile)
+    (1, 32, 64, 160, 1, 1, False),   # halo kernel, fused upsample to 64x64
+    (5, 8, 256, 192, 1, 0, True),    # halo kernel, 4 whole 8x8 images per tile + an M tail tile
+    (1, 4, 64, 64, 1, 1, False),     # upsample to 8x8: one image, 192 of 256 tile rows unused
 ])
 def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
     g = torch.Generator().manual_seed(B * 100 + H + Cin)
