@@ -29,8 +29,9 @@ constexpr int WTM = 64, WTN = 80;
 constexpr int HSLOTS = 448;                   // 7 DMA pieces of 64 slots
 constexpr int HPIECES = HSLOTS * 8 / 512;
 constexpr int HBYTES = HSLOTS * 128;
-constexpr int WBYTES = BN * 128;
-constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage
+constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage ...
+constexpr int WPIECES_PAD = 24;               // ... padded to 3 per wave: the K loop stays branch-free
+constexpr int WBYTES = WPIECES_PAD * 1024;
 constexpr int SMEM = 2 * HBYTES + 2 * WBYTES;
 static_assert(SMEM <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
 constexpr unsigned NOSRC = 0xffffffffu;
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware order: workgroups of one XCD (blockIdx % 8) take consecutive items, n fastest, so the
-    // n-tiles that share an input halo read it from the same L2.
+    // Persistent workgroups, one per CU, walking the work items (output tile x K split) with stride
+    // gridDim.x.  XCD-aware order: workgroups of one XCD (blockIdx % 8) take consecutive items, n fastest,
+    // so the n-tiles that share an input halo read it from the same L2.
     int work = blockIdx.x;
     {
         const int nblk = gridDim.x;
@@ -54,12 +56,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
         work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int split = work / ntiles;
-    const int t = work - split * ntiles;
-    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nwork = ntiles * p.splitk;
+    if (work >= nwork) return;
     const int S = p.Cin >> 6;
-    const int s_begin = (int)((long)S * split / p.splitk), s_end = (int)((long)S * (split + 1) / p.splitk);
 
     // tile geometry: BM / PIX pieces of RW whole OUTPUT rows (more than one piece only when an image has
     // fewer than 256 pixels).  With the fused nearest-2x upsample (p.up = 1) the halo lives in the
@@ -75,68 +74,88 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     const char* Xb = (const char*)p.X;
     const char* Wg = (const char*)p.W;
 
-    // ---- LDS-DMA source descriptors (byte offsets; NOSRC = zero page) ------------------------------
-    unsigned hoff[HPIECES];
+    // ---- LDS-DMA source descriptors ---------------------------------------------------------------------
+    // Item-independent part, computed once (runtime divisions by the halo pitch): for DMA piece j this lane
+    // fills chunk position (L & 7) of halo slot L >> 3 = (piece i, halo row hy, halo column hx).
+    //   hrel[j] = byte offset of that chunk relative to the piece's first input row (may be negative; a
+    //   multiple of 16) | piece i in bits 0-1 | bit 2: first halo row | bit 3: last halo row.
+    //   Slots beyond the halo and the left/right padding columns: HREL_ZERO.
+    // Output width and image size are powers of two (checked on the host), so the per-item part is shifts.
+    constexpr int HREL_ZERO = (int)0x80000000;
+    const int lgW = __builtin_ctz(Wo), lgHW = __builtin_ctz(HWo);
+    const int RWin = RW >> up;                   // input rows under one piece
+    int hrel[HPIECES];
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) {
         const int L = j * 512 + tid;
         const int slot = L >> 3, cpos = L & 7;
-        unsigned off = NOSRC;
-        if (slot < HP) {
-            const int i = slot / PP, rem = slot - i * PP;
-            const int hy = rem / PW, hx = rem - hy * PW;
-            const int mp = m0 + i * PIX;
-            const int b = mp / HWo, oy0 = (mp - b * HWo) / Wo;
-            const int y = (oy0 >> up) + hy - 1, x = hx - 1;
-            if (mp < p.M && y >= 0 && y < p.Hin && x >= 0 && x < p.Win)
-                off = (unsigned)((((long)b * p.Hin + y) * p.Win + x) * p.Cin * 2 + ((cpos ^ (slot & 7)) << 4));
-        }
-        hoff[j] = off;
+        const int i = slot / PP, rem = slot - i * PP;
+        const int hy = rem / PW, hx = rem - hy * PW;
+        const bool ok = slot < HP && hx >= 1 && hx <= p.Win;
+        hrel[j] = ok ? ((((hy - 1) * p.Win + (hx - 1)) * p.Cin * 2 + ((cpos ^ (slot & 7)) << 4)) | i |
+                        (hy == 0 ? 4 : 0) | (hy == RWin + 1 ? 8 : 0))
+                     : HREL_ZERO;
     }
-    unsigned woffs[3];
+
+    // ---- per-item state: tile origin, K range, source offsets -------------------------------------------
+    int split = 0, m0 = 0, n0 = 0, s_begin = 0, s_end = 0;
+    unsigned hoff[HPIECES];                      // byte offsets into X; NOSRC = zero page
+    unsigned woffs[3];                           // byte offsets into W
+    auto setup = [&](int w) {
+        split = w / ntiles;
+        const int t = w - split * ntiles;
+        const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+        s_begin = (int)((long)S * split / p.splitk);
+        s_end = (int)((long)S * (split + 1) / p.splitk);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int pc = wave + i * 8;
-        const int n = n0 + pc * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (lane >> 3);
-        woffs[i] = (pc < WPIECES && n < p.N) ? (unsigned)((long)n * p.ldw * 2 + (c << 4)) : NOSRC;
-    }
-    auto issue_h = [&](int j, int s, char* hb) {
-        const void* src = hoff[j] != NOSRC ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
-        glds16(src, hb + j * 8192 + wave * 1024);
-    };
-    auto issue_w = [&](int kk, char* wb) {       // kk = slice * 9 + tap
+        for (int j = 0; j < HPIECES; ++j) {
+            const int mp = m0 + (hrel[j] & 3) * PIX;                   // first output pixel of the piece
+            const int b = mp >> lgHW;
+            const int ybase = (mp & (HWo - 1)) >> (lgW + up);          // its first input row
+            const bool ok = hrel[j] != HREL_ZERO && mp < p.M && !((hrel[j] & 4) && ybase == 0) &&
+                            !((hrel[j] & 8) && ybase + RWin == p.Hin);
+            const unsigned base = (unsigned)(((long)b * p.Hin + ybase) * p.Win * p.Cin * 2);
+            hoff[j] = ok ? base + (unsigned)(hrel[j] & ~15) : NOSRC;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pc = wave + i * 8;
-            if (pc < WPIECES) {                  // wave-uniform
-                const void* src = woffs[i] != NOSRC ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
-                glds16(src, wb + pc * 1024);
-            }
+            const int n = n0 + pc * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (lane >> 3);
+            woffs[i] = (pc < WPIECES && n < p.N) ? (unsigned)((long)n * p.ldw * 2 + (c << 4)) : NOSRC;
         }
     };
+    auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch (zero page), keeps the loop branch-free
+        const void* src = (hoff[j] != NOSRC && s >= 0) ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
+        glds16(src, hb + j * 8192 + wave * 1024);
+    };
+    auto issue_w1 = [&](int i, int kk, char* wb) {   // kk = slice * 9 + tap; < 0: nothing to fetch
+        const int pc = wave + i * 8;                  // pieces 20..23 are padding (zero page -> unused LDS)
+        const void* src = (woffs[i] != NOSRC && kk >= 0) ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
+        glds16(src, wb + pc * 1024);
+    };
+    auto issue_w = [&](int kk, char* wb) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) issue_w1(i, kk, wb);
+    };
 
-    // ---- fragment addressing --------------------------------------------------------------------
+    // ---- fragment addressing (the same for every item) --------------------------------------------------
     const int wm = wave & 3, wn = wave >> 2;
     const int lrow = lane & 15, lq = lane >> 4;
-    int hbase[TM], hrow[TM], hcol[TM];            // this lane's pixels: piece base slot (+1,+1), row, column
+    int hbase[TM], hrc[TM];                       // this lane's pixels: piece base slot (+1,+1), row << 16 | column
 #pragma unroll
     for (int f = 0; f < TM; ++f) {
         const int pt = wm * WTM + f * 16 + lrow;
         const int i = pt / PIX, rem = pt - i * PIX;
-        hrow[f] = rem / Wo;
-        hcol[f] = rem - hrow[f] * Wo;
+        hrc[f] = (rem >> lgW) << 16 | (rem & (Wo - 1));
         hbase[f] = i * PP + PW + 1;
     }
     const int wfrag = (wn * WTN + lrow) * 128;
     const int wswz0 = (lq ^ (lane & 7)) << 4;     // k-step 1 = ^ 64
 
     f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
 #pragma unroll
@@ -151,126 +170,163 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     char* const Wb0 = smem + 2 * HBYTES;
     char* const Wb1 = Wb0 + WBYTES;
 
-    // prologue: halo of the first slice + first W stage
+    // Buffer parities run on across items: the halo buffer / W stage an item starts in is the one its
+    // predecessor was not reading in its last K tile, so the next item's first halo and W stage can be in
+    // flight under the predecessor's epilogue stores.
+    int hsel = 0, wsel = 0;
+    setup(work);
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, Hb0);
     issue_w(s_begin * 9, Wb0);
+    bool stores_pending = false;                  // exactly FULL_STORES stores were issued after that DMA
+    constexpr int FULL_STORES = (TN / 2 + TN % 2) * TM;
 
-    int wsel = 0;
-    for (int s = s_begin; s < s_end; ++s) {
-        const bool odd = (s - s_begin) & 1;
-        const char* hcur = odd ? Hb1 : Hb0;
-        char* hnext = odd ? Hb0 : Hb1;
-        const bool more = s + 1 < s_end;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // everything issued one K tile ago has landed; every wave is done reading the buffers that
-            // are refilled below (W stage of tile kt-1, halo of slice s-1)
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const char* wcur = wsel ? Wb1 : Wb0;
-            char* wnext = wsel ? Wb0 : Wb1;
-            int xa[TM];
-#pragma unroll
-            for (int f = 0; f < TM; ++f) {
-                const int hp = hbase[f] + ((hrow[f] + (tap / 3 - 1)) >> up) * PW + ((hcol[f] + (tap % 3 - 1)) >> up);
-                xa[f] = hp * 128 + ((lq ^ (hp & 7)) << 4);
-                xf0[f] = *(const bf16x8*)(hcur + xa[f]);
-            }
-#pragma unroll
-            for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (tap < HPIECES && more) issue_h(tap, s + 1, hnext);
-            if (tap < 8) issue_w(s * 9 + tap + 1, wnext);
-            else if (more) issue_w((s + 1) * 9, wnext);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
-#pragma unroll
-            for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
-            mfmas(xf0, wf0);
-            mfmas(xf1, wf1);
-            wsel ^= 1;
-        }
-    }
-
-    // ---- epilogue (accumulator layout as gemm_kernel: lane owns 4 consecutive channels of one pixel) --
-    if (p.splitk > 1) {
-        float* slab = p.slab + (long)split * p.M * p.N;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + lq * 4;
-            if (n >= p.N) continue;
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int m = m0 + wm * WTM + b * 16 + lrow;
-                if (m >= p.M) continue;
-                *(f32x4*)(slab + (long)m * p.N + n) = acc[a][b];
-            }
-        }
-        return;
-    }
-    if (p.R) {
-        u32x2 rr[TN][TM];
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int n = min(n0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int m = min(m0 + wm * WTM + b * 16 + lrow, p.M - 1);
-                rr[a][b] = *(const u32x2*)(p.R + (long)m * p.ldr + n);
-            }
-        }
+    while (true) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                acc[a][b][0] += bflo(rr[a][b][0]); acc[a][b][1] += bfhi(rr[a][b][0]);
-                acc[a][b][2] += bflo(rr[a][b][1]); acc[a][b][3] += bfhi(rr[a][b][1]);
+            for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int s = s_begin; s < s_end; ++s) {
+            const char* hcur = hsel ? Hb1 : Hb0;
+            char* hnext = hsel ? Hb0 : Hb1;
+            const bool more = s + 1 < s_end;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // Everything issued one K tile ago has landed; every wave is done reading the buffers that
+                // are refilled below (W stage of tile kt-1, halo of slice s-1).  vmcnt counts stores too and
+                // retires in order: on an item's first tile a COUNTED wait leaves the predecessor's epilogue
+                // stores, issued after this tile's DMA, in flight.
+                if (tap == 0 && s == s_begin && stores_pending) wait_vmcnt<FULL_STORES>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* wcur = wsel ? Wb1 : Wb0;
+                char* wnext = wsel ? Wb0 : Wb1;
+                int xa[TM];
+#pragma unroll
+                for (int f = 0; f < TM; ++f) {
+                    const int hp = hbase[f] + (((hrc[f] >> 16) + (tap / 3 - 1)) >> up) * PW +
+                                   (((hrc[f] & 0xffff) + (tap % 3 - 1)) >> up);
+                    xa[f] = hp * 128 + ((lq ^ (hp & 7)) << 4);
+                    xf0[f] = *(const bf16x8*)(hcur + xa[f]);
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
+                issue_w(tap < 8 ? s * 9 + tap + 1 : (more ? (s + 1) * 9 : -1), wnext);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
+                mfmas(xf0, wf0);
+                mfmas(xf1, wf1);
+                wsel ^= 1;
             }
-    }
-    if (p.bias) {
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int n = min(n0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
-            f32x4 bv = *(const f32x4*)(p.bias + n);
-            if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
-#pragma unroll
-            for (int b = 0; b < TM; ++b) acc[a][b] += bv;
+            hsel ^= 1;
         }
-    }
-    // v_permlane16_swap pairs two adjacent 16-channel tiles: 16 contiguous bytes per lane and store
-    const bool wide_ok = (p.ldc & 7) == 0;
-    auto store_narrow = [&](int a) {
-        const int n = n0 + wn * WTN + a * 16 + lq * 4;
-        if (n >= p.N) return;
+
+        // ---- epilogue, phase A: every LOAD the epilogue needs, folded into the accumulators now so that
+        // no ordinary load is outstanding once the next item's LDS-DMA is in flight ----------------------
+        // (accumulator layout as gemm_kernel: a lane owns 4 consecutive channels of one pixel per 16x16 tile)
+        const int em0 = m0, en0 = n0, esplit = split;
+        if (p.splitk == 1) {
+            if (p.R) {
+                u32x2 rr[TN][TM];
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const int m = m0 + wm * WTM + b * 16 + lrow;
-            const f32x4 v = acc[a][b];
-            u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            if (m < p.M) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+                for (int a = 0; a < TN; ++a) {
+                    const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const int m = min(em0 + wm * WTM + b * 16 + lrow, p.M - 1);
+                        rr[a][b] = *(const u32x2*)(p.R + (long)m * p.ldr + n);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        acc[a][b][0] += bflo(rr[a][b][0]); acc[a][b][1] += bfhi(rr[a][b][0]);
+                        acc[a][b][2] += bflo(rr[a][b][1]); acc[a][b][3] += bfhi(rr[a][b][1]);
+                    }
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+                    f32x4 bv = *(const f32x4*)(p.bias + n);
+                    if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) acc[a][b] += bv;
+                }
+            }
         }
-    };
+
+        // ---- next item: descriptors + its first halo and W stage in flight before this item's stores ----
+        work += gridDim.x;
+        const bool more_work = work < nwork;
+        const bool wide_ok = (p.ldc & 7) == 0;
+        if (more_work) {
+            setup(work);
+            // The buffers refilled here were last read one slice / one K tile before the final one, i.e.
+            // before a barrier every wave has passed: no extra barrier.
+            char* hb = hsel ? Hb1 : Hb0;
 #pragma unroll
-    for (int a = 0; a < TN; a += 2) {
-        const int nb = n0 + wn * WTN + a * 16;
-        if (a + 1 < TN && wide_ok && nb + 32 <= p.N) {
+            for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, hb);
+            issue_w(s_begin * 9, wsel ? Wb1 : Wb0);
+            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N);
+        }
+
+        // ---- epilogue, phase B: stores only ----------------------------------------------------------------
+        if (p.splitk > 1) {
+            float* slab = p.slab + (long)esplit * p.M * p.N;
 #pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int m = m0 + wm * WTM + b * 16 + lrow;
-                const f32x4 vx = acc[a][b], vy = acc[a + 1 < TN ? a + 1 : a][b];
-                const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
-                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
-                if (m < p.M) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+            for (int a = 0; a < TN; ++a) {
+                const int n = en0 + wn * WTN + a * 16 + lq * 4;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = em0 + wm * WTM + b * 16 + lrow;
+                    if (m >= p.M) continue;
+                    *(f32x4*)(slab + (long)m * p.N + n) = acc[a][b];
+                }
             }
         } else {
-            store_narrow(a);
-            if (a + 1 < TN) store_narrow(a + 1);
+            // v_permlane16_swap pairs two adjacent 16-channel tiles: 16 contiguous bytes per lane and store
+            auto store_narrow = [&](int a) {
+                const int n = en0 + wn * WTN + a * 16 + lq * 4;
+                if (n >= p.N) return;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = em0 + wm * WTM + b * 16 + lrow;
+                    const f32x4 v = acc[a][b];
+                    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    if (m < p.M) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+                }
+            };
+#pragma unroll
+            for (int a = 0; a < TN; a += 2) {
+                const int nb = en0 + wn * WTN + a * 16;
+                if (a + 1 < TN && wide_ok && nb + 32 <= p.N) {
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const int m = em0 + wm * WTM + b * 16 + lrow;
+                        const f32x4 vx = acc[a][b], vy = acc[a + 1 < TN ? a + 1 : a][b];
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
+                        if (m < p.M) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+                    }
+                } else {
+                    store_narrow(a);
+                    if (a + 1 < TN) store_narrow(a + 1);
+                }
+            }
         }
+        if (!more_work) break;
     }
 }
 
@@ -292,6 +348,7 @@ bool sd_conv_halo_applicable(const GemmArgs& a) {
     const int RW = H < BM / W ? H : BM / W;
     const int PIX = RW * W;
     if (BM % PIX || (H * W) % PIX || (a.up && (RW & 1))) return false;
+    if ((W & (W - 1)) || ((H * W) & (H * W - 1))) return false;   // the kernel decodes pixels with shifts
     if ((BM / PIX) * ((RW >> a.up) + 2) * (a.Win + 2) > HSLOTS) return false;
     if ((long)a.M * a.Cin * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
     return true;
@@ -330,7 +387,10 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    const int grid = a.tiles_m * a.tiles_n * a.splitk;
+    static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
+    a.tune = tune;
+    int grid = a.tiles_m * a.tiles_n * a.splitk;
+    if (grid > 256) grid = 256;                  // persistent: one 8-wave workgroup per CU
     hipLaunchKernelGGL(conv_halo_kernel, dim3(grid), dim3(512), SMEM, stream, a);
     if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());

@@ -1,1 +1,1 @@
-for t in 0 2; do echo "--- SD_GEMM_BIG=$t"; SD_GEMM_BIG=$t timeout -k 10 200 python tools/bench_ops.py --only gemm 2>&1 | grep -E "^gemm"; done
+for t in 0 4 8 12; do echo "--- SD_GEMM_TUNE=$t"; SD_GEMM_TUNE=$t timeout -k 10 200 python tools/bench_ops.py --only conv 2>&1 | grep -E "^conv res= 32  1920|^conv res= 64   320->  320 s1"; done
