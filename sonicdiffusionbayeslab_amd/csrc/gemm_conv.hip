@@ -193,7 +193,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     // One K tile = two 32-deep k-steps.  The fragments of k-step 0 are read BEFORE the next tile's
     // LDS-DMA is issued (a glds costs the issuing wave ~60 cycles each, which hides the ds_read
     // latency), k-step 1's fragments are read under k-step 0's MFMAs.
-    bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    constexpr bool FRAG_DB = TM * TN * 4 + (TM + TN) * 8 <= 200;   // accumulators + two fragment sets
+    bf16x8 xf0[TM], wf0[TN], xf1[FRAG_DB ? TM : 1], wf1[FRAG_DB ? TN : 1];
     auto load_frags = [&](const char* sb, int ks, bf16x8* xf, bf16x8* wf) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
@@ -237,11 +238,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < KT) stage(kt_begin + kt + 1, (g + kt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(sb, 1, xf1, wf1);
-            if (p.tune & 1) __builtin_amdgcn_s_setprio(1);
-            mfmas(xf0, wf0);
-            mfmas(xf1, wf1);
-            if (p.tune & 1) __builtin_amdgcn_s_setprio(0);
+            if (FRAG_DB) {
+                load_frags(sb, 1, xf1, wf1);
+                mfmas(xf0, wf0);
+                mfmas(xf1, wf1);
+            } else {                 // register budget: one fragment set, reloaded between the k-steps
+                mfmas(xf0, wf0);
+                load_frags(sb, 1, xf0, wf0);
+                mfmas(xf0, wf0);
+            }
         }
         g += KT;
     } else {
@@ -382,6 +387,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64);
         auto geglu_tile = [&](int a, int b) -> u32x2 {      // output tile of accumulator pair (a, a+1)
             const f32x4 va = acc[a][b], vg = acc[a + 1][b];
+#ifdef GEGLU_NOGELU
+            return u32x2{pack2bf(va[0] * vg[0], va[1] * vg[1]), pack2bf(va[2] * vg[2], va[3] * vg[3])};
+#endif
             return u32x2{pack2bf(va[0] * gelu_erf_f(vg[0]), va[1] * gelu_erf_f(vg[1])),
                          pack2bf(va[2] * gelu_erf_f(vg[2]), va[3] * gelu_erf_f(vg[3]))};
         };
@@ -510,7 +518,9 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     if (epi == EPI_GEGLU) {
         SD_REQUIRE(a.N % 32 == 0, "geglu gemm: N=%d must be a multiple of 32", a.N);
         if (big_tile_ok(a.M, a.N, 128)) return launch<256, 128, 4, 2, 3, AMODE_GEMM, EPI_GEGLU>(a, stream);
-        if (big_tile_mode() == 2 && a.N % 256 == 0) return launch<256, 256, 4, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
+        // 256 x 256 (one 8-wave workgroup per CU): half the LDS-fill bytes per flop of the 128 x 128 tile,
+        // measured 5-20 % faster at every SD-1.5 GEGLU shape (N = 2560 / 5120 / 10240)
+        if (big_tile_mode() != 3 && a.N % 256 == 0) return launch<256, 256, 4, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
         return launch<128, 128, 2, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
     }
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
