@@ -134,11 +134,15 @@ class DPMSolverOracle(_Base):
     def step_index(self):
         return self._step_index
 
-    def set_timesteps(self, num_inference_steps: int, device=None):
+    def set_timesteps(self, num_inference_steps: int = None, device=None, timesteps=None):
+        """``timesteps``: custom schedule (diffusers 0.32.1 DPMSolverMultistepScheduler.set_timesteps;
+        used by the two-scheduler pipeline, ``src/models.py:488-492``) [upstream-recall]."""
         T = self.config["num_train_timesteps"]
         last_timestep = T            # lambda_min_clipped = -inf
         spacing = self.config.get("timestep_spacing", "linspace")
-        if spacing == "linspace":
+        if timesteps is not None:
+            ts = np.array([int(t) for t in timesteps]).astype(np.int64)
+        elif spacing == "linspace":
             ts = np.linspace(0, last_timestep - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
         elif spacing == "leading":
             step_ratio = last_timestep // (num_inference_steps + 1)
@@ -178,7 +182,10 @@ class DPMSolverOracle(_Base):
 
     # src/schedulers.py:14-96 (epsilon prediction, no thresholding)
     def convert_model_output(self, model_output, sample):
-        sigma = self.sigmas[self.step_index]
+        # The variant pipelines call this on a scheduler that has not stepped yet (src/models.py:603-611):
+        # the reference then indexes ``sigmas[None]`` and fails on a shape mismatch.  Restated with index 0
+        # so that the hand-off runs; with the shipped configs the entry is shifted out before it is used.
+        sigma = self.sigmas[self.step_index if self.step_index is not None else 0]
         alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(sigma)
         x0_pred = (sample - sigma_t * model_output) / alpha_t
         if self.config["algorithm_type"] in ("dpmsolver++", "sde-dpmsolver++"):

@@ -13,7 +13,9 @@ Timing keeps the reference's definition -- wall-clock of the loop only (``:208,2
 brackets it with device synchronisation so the number is real.
 
 ``output_type="pt"`` decodes through the libsdhip AutoencoderKL decoder (``vae.py``, SURVEY 8f row 1;
-outside the timed loop, as in the reference).  Still out of scope: the CLIP text
+outside the timed loop, as in the reference).  The three variant pipelines of ``src/models.py:338-1467``
+(two schedulers, interleaved schedulers, skipped timesteps) are host-only control flow over
+the same kernels and live at the bottom of this file.  Still out of scope: the CLIP text
 encoder -- prompts are encoded by a pluggable ``text_encoder`` (default: a deterministic seeded
 stand-in, since no CLIP weights exist offline).
 """
@@ -187,15 +189,11 @@ class StableDiffusionModel:
             return result, execution_time, x0_preds
         return result, x0_preds
 
-    # -- the sampling loop (src/models.py:32-335) ----------------------------------------------
-    @torch.no_grad()
-    def call(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
-             num_inference_steps: int = 50, timesteps=None, sigmas=None, guidance_scale: float = 7.5,
-             negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None,
-             latents: Optional[torch.Tensor] = None, prompt_embeds: Optional[torch.Tensor] = None,
-             negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "pil",
-             return_dict: bool = True, guidance_rescale: float = 0.0, step_noise: Optional[torch.Tensor] = None,
-             collect_x0: bool = True, **kwargs):
+    # -- pieces shared by the four pipelines ------------------------------------------------------
+    def _begin(self, prompt, height, width, guidance_scale, negative_prompt, num_images_per_prompt, prompt_embeds,
+               negative_prompt_embeds, guidance_rescale=0.0, timesteps=None, sigmas=None):
+        """Steps 0-3 of the reference's ``call`` (``src/models.py:110-160``): argument checks, batch size,
+        prompt encoding, CFG concat; uploads the prompt K/V projections.  Returns (device, batch, do_cfg, ctx)."""
         if guidance_rescale != 0.0:
             raise NotImplementedError("guidance_rescale is never used by the reference (src/models.py:53)")
         if num_images_per_prompt != 1 or timesteps is not None or sigmas is not None:
@@ -208,29 +206,63 @@ class StableDiffusionModel:
         if height != cfgu.sample_size * 8 or width != cfgu.sample_size * 8:
             raise ValueError("resolution is fixed by the UNet sample_size")
         self._guidance_scale = guidance_scale
-
         if prompt is not None and isinstance(prompt, str):
             batch_size = 1
         elif prompt is not None:
             batch_size = len(prompt)
         else:
             batch_size = prompt_embeds.shape[0]
-
         do_cfg = self.do_classifier_free_guidance
         prompt_embeds, negative_prompt_embeds = self.encode_prompt(
             prompt, device, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)
         ctx = torch.cat([negative_prompt_embeds, prompt_embeds]) if do_cfg else prompt_embeds   # :154-155
+        return device, batch_size, do_cfg, ctx
+
+    def _eps_buffer(self, unet_batch, device):
+        c = self.unet_config
+        return torch.empty((unet_batch, c.out_channels, c.sample_size, c.sample_size), dtype=torch.float32, device=device)
+
+    def _finish(self, latents, x0_preds, output_type, return_dict, execution_time):
+        """``src/models.py:287-335``: decode (outside the timed loop), post-process, 3-tuple."""
+        if output_type == "latent":
+            image = latents
+            image_x0 = x0_preds
+        elif output_type == "pt":
+            vae = self._ensure_vae()
+            inv = 1.0 / self.vae_config.scaling_factor
+            image = (vae.decode(latents, inv) / 2 + 0.5).clamp(0, 1)                               # :288,:312
+            # the reference decodes EVERY stored x0 prediction as well (:296-302)
+            image_x0 = [(vae.decode(x, inv) / 2 + 0.5).clamp(0, 1) for x in x0_preds]
+        else:
+            raise NotImplementedError(f"output_type {output_type!r}: 'latent' and 'pt' are built")
+        if not return_dict:
+            return (image, None), execution_time, image_x0
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0
+
+    # -- the sampling loop (src/models.py:32-335) ----------------------------------------------
+    @torch.no_grad()
+    def call(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
+             num_inference_steps: int = 50, timesteps=None, sigmas=None, guidance_scale: float = 7.5,
+             negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None,
+             latents: Optional[torch.Tensor] = None, prompt_embeds: Optional[torch.Tensor] = None,
+             negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "pil",
+             return_dict: bool = True, guidance_rescale: float = 0.0, step_noise: Optional[torch.Tensor] = None,
+             collect_x0: bool = True, **kwargs):
+        device, batch_size, do_cfg, ctx = self._begin(prompt, height, width, guidance_scale, negative_prompt,
+                                                      num_images_per_prompt, prompt_embeds, negative_prompt_embeds,
+                                                      guidance_rescale, timesteps, sigmas)
+        cfgu = self.unet_config
         unet_batch = ctx.shape[0]
 
         self.scheduler.set_timesteps(num_inference_steps, device=device)                        # :167-169
         ts_host = list(self.scheduler._timesteps_list)
-        latents = self.prepare_latents(batch_size, cfgu.in_channels, height, width, device, generator, latents)
+        latents = self.prepare_latents(batch_size, cfgu.in_channels, cfgu.sample_size * 8, cfgu.sample_size * 8,
+                                       device, generator, latents)
 
         dc = self._deepcache
         self.unet.set_deepcache(dc.cache_branch_id if dc is not None else -1)
         self.unet.set_context(ctx)
-        eps = torch.empty((unet_batch, cfgu.out_channels, cfgu.sample_size, cfgu.sample_size),
-                          dtype=torch.float32, device=device)
+        eps = self._eps_buffer(unet_batch, device)
         self._num_timesteps = len(ts_host)
         x0_preds = []
         is_lcm = hasattr(self.scheduler, "config") and "timestep_scaling" in self.scheduler.config
@@ -257,21 +289,210 @@ class StableDiffusionModel:
                     x0_preds.append(x0[0:1])
         torch.cuda.synchronize(device)
         execution_time = time.time() - start_time                                                 # :284-285
+        return self._finish(latents, x0_preds, output_type, return_dict, execution_time)
 
-        if output_type == "latent":
-            image = latents
-            image_x0 = x0_preds
-        elif output_type == "pt":
-            vae = self._ensure_vae()
-            inv = 1.0 / self.vae_config.scaling_factor
-            image = (vae.decode(latents, inv) / 2 + 0.5).clamp(0, 1)                               # :288,:312
-            # the reference decodes EVERY stored x0 prediction as well (:296-302)
-            image_x0 = [(vae.decode(x, inv) / 2 + 0.5).clamp(0, 1) for x in x0_preds]
-        else:
-            raise NotImplementedError(f"output_type {output_type!r}: 'latent' and 'pt' are built")
-        if not return_dict:
-            return (image, None), execution_time, image_x0
-        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0
+
+# --------------------------------------------------------------------------------------------------
+# Variant pipelines: host-only control flow over the same kernels.
+# --------------------------------------------------------------------------------------------------
+def _is_dpm(s) -> bool:
+    return hasattr(s, "model_outputs") and hasattr(s, "convert_model_output")
+
+
+def _push_history(sched, noise_pred, latents):
+    """History hand-off (``src/models.py:603-611``, ``:1025-1033``, ``:1045-1053``): shift the other
+    scheduler's ``model_outputs`` and append its conversion of this noise prediction.  ``sample=latents``
+    is the latents AFTER the step, as the reference writes it."""
+    out = sched.convert_model_output(noise_pred, sample=latents)
+    model_output = out[0] if isinstance(out, tuple) else out
+    for k in range(sched.config.solver_order - 1):
+        sched.model_outputs[k] = sched.model_outputs[k + 1]
+    sched.model_outputs[-1] = model_output
+
+
+class _VariantBase(StableDiffusionModel):
+    """Shared step of the variant loops: UNet forward, then CFG combine + ``scheduler.step`` in the one fused
+    launch, returning the new latents and the CFG-combined noise prediction the hand-off needs."""
+
+    def _step_with(self, sched, eps, latents, t, unet_batch, do_cfg, guidance_scale, eta, generator, x0_preds):
+        self.unet.forward_latents(latents, unet_batch, float(t), out=eps, cache_mode=CACHE_OFF)
+        step = sched.step_fused(eps, guidance_scale, latents, t, cfg=do_cfg, eta=eta, generator=generator)
+        if len(step) == 2:
+            x0_preds.append(step[1][0:1])
+        return step[0]
+
+    @staticmethod
+    def _combined(eps, do_cfg, guidance_scale):
+        if not do_cfg:
+            return eps
+        u, c = eps.chunk(2)
+        return u + guidance_scale * (c - u)                                                         # :238-242
+
+
+@models_registry.add_to_registry("stable_diffusion_model_two_schedulers")
+class StableDiffusionModelTwoSchedulers(_VariantBase):
+    """``src/models.py:338-730``: ``scheduler_first`` for the first ``num_step_switch`` steps, then
+    ``scheduler_second`` from the timestep ``switch_timestamp`` selects.  The second scheduler is handed the
+    FIRST scheduler's timesteps as a custom schedule (``:488-492``; ``num_inference_steps_second`` is
+    accepted and, as in the reference, not used)."""
+    scheduler_first = None
+    scheduler_second = None
+
+    @staticmethod
+    def switch_timestamp(timesteps_first, timesteps_second, num_step_switch, type_switch="closest"):
+        """``src/models.py:704-730``."""
+        first = [int(t) for t in timesteps_first][:num_step_switch]
+        second = [int(t) for t in timesteps_second]
+        pivot = first[-1]
+        if type_switch == "closest":
+            dist = [abs(t - pivot) for t in second]
+            second = second[dist.index(min(dist)):]
+        elif type_switch == "left_closest":
+            idx = [i for i, t in enumerate(second) if t - pivot >= 0]
+            second = second[idx[-1]:]
+        elif type_switch == "right_closest":
+            idx = [i for i, t in enumerate(second) if t - pivot <= 0]
+            second = second[idx[0]:]
+        return first, second
+
+    @torch.no_grad()
+    def call(self, prompt=None, height=None, width=None, num_inference_steps_first: int = 50,
+             num_inference_steps_second: int = 50, num_step_switch: int = 10, type_switch: str = "closest",
+             timesteps=None, sigmas=None, guidance_scale: float = 7.5, negative_prompt=None,
+             num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+             negative_prompt_embeds=None, output_type: str = "pil", return_dict: bool = True,
+             guidance_rescale: float = 0.0, **kwargs):
+        if self.scheduler_first is None or self.scheduler_second is None:
+            raise ValueError("scheduler_first / scheduler_second must be set (two_schedulers.py:44-62)")
+        device, batch_size, do_cfg, ctx = self._begin(prompt, height, width, guidance_scale, negative_prompt,
+                                                      num_images_per_prompt, prompt_embeds, negative_prompt_embeds,
+                                                      guidance_rescale, timesteps, sigmas)
+        c = self.unet_config
+        unet_batch = ctx.shape[0]
+        self.scheduler_first.set_timesteps(num_inference_steps_first, device=device)               # :484-487
+        self.scheduler_second.set_timesteps(device=device, timesteps=self.scheduler_first._timesteps_list)  # :488-492
+        first, second = self.switch_timestamp(self.scheduler_first._timesteps_list,
+                                              self.scheduler_second._timesteps_list, num_step_switch, type_switch)
+        self.scheduler = self.scheduler_first                     # prepare_latents reads init_noise_sigma
+        latents = self.prepare_latents(batch_size, c.in_channels, c.sample_size * 8, c.sample_size * 8, device,
+                                       generator, latents)
+        self.unet.set_deepcache(-1)
+        self.unet.set_context(ctx)
+        eps = self._eps_buffer(unet_batch, device)
+        self._num_timesteps = len(first) + len(second)                                              # :545
+        x0_preds = []
+        hand_off = _is_dpm(self.scheduler_second)
+        torch.cuda.synchronize(device)
+        start_time = time.time()
+        for i, t in enumerate(first + second):                                                      # :550
+            in_first = i < len(first)
+            sched = self.scheduler_first if in_first else self.scheduler_second
+            latents = self._step_with(sched, eps, latents, t, unet_batch, do_cfg, guidance_scale, eta, generator,
+                                      x0_preds)
+            if in_first and hand_off:                                                               # :603-611
+                _push_history(self.scheduler_second, self._combined(eps, do_cfg, guidance_scale), latents)
+        torch.cuda.synchronize(device)
+        return self._finish(latents, x0_preds, output_type, return_dict, time.time() - start_time)
+
+
+@models_registry.add_to_registry("stable_diffusion_model_interliving_schedulers")
+class StableDiffusionModelInterlivingSchedulers(_VariantBase):
+    """``src/models.py:733-1136``: groups of ``solver_order`` steps of ``scheduler_main`` listed in
+    ``interliving_steps`` are replaced by one step of ``scheduler_inter`` at the group's first timestep; each
+    scheduler's multistep history is fed the other's noise predictions."""
+    scheduler_main = None
+    scheduler_inter = None
+
+    @staticmethod
+    def interleave_plan(timesteps_main, solver_order, interliving_steps):
+        """``src/models.py:952-966``: returns (timesteps that run, those of them the inter scheduler takes)."""
+        keep, t_inter = [], []
+        for i, t in enumerate(int(x) for x in timesteps_main):
+            if i // solver_order in interliving_steps:
+                if i % solver_order != 0:
+                    continue
+                t_inter.append(t)
+            keep.append(t)
+        return keep, t_inter
+
+    @torch.no_grad()
+    def call(self, prompt=None, height=None, width=None, num_inference_steps: int = 50, interliving_steps=None,
+             timesteps=None, sigmas=None, guidance_scale: float = 7.5, negative_prompt=None,
+             num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+             negative_prompt_embeds=None, output_type: str = "pil", return_dict: bool = True,
+             guidance_rescale: float = 0.0, **kwargs):
+        if self.scheduler_main is None or self.scheduler_inter is None:
+            raise ValueError("scheduler_main / scheduler_inter must be set (interliving_exp.py:41-62)")
+        interliving_steps = list(interliving_steps or [])
+        device, batch_size, do_cfg, ctx = self._begin(prompt, height, width, guidance_scale, negative_prompt,
+                                                      num_images_per_prompt, prompt_embeds, negative_prompt_embeds,
+                                                      guidance_rescale, timesteps, sigmas)
+        c = self.unet_config
+        unet_batch = ctx.shape[0]
+        order = self.scheduler_main.config.solver_order
+        self.scheduler_main.set_timesteps(num_inference_steps, device=device)                       # :880-886
+        self.scheduler_inter.set_timesteps(num_inference_steps // order, device=device)             # :888-894
+        keep, t_inter = self.interleave_plan(self.scheduler_main._timesteps_list, order, interliving_steps)
+        self.scheduler = self.scheduler_main
+        latents = self.prepare_latents(batch_size, c.in_channels, c.sample_size * 8, c.sample_size * 8, device,
+                                       generator, latents)
+        self.unet.set_deepcache(-1)
+        self.unet.set_context(ctx)
+        eps = self._eps_buffer(unet_batch, device)
+        self._num_timesteps = len(self.scheduler_main._timesteps_list) - len(interliving_steps)     # :946
+        x0_preds = []
+        torch.cuda.synchronize(device)
+        start_time = time.time()
+        for t in keep:
+            if t in t_inter:                                                                        # :1008-1034
+                latents = self._step_with(self.scheduler_inter, eps, latents, t, unet_batch, do_cfg, guidance_scale,
+                                          eta, generator, x0_preds)
+                _push_history(self.scheduler_main, self._combined(eps, do_cfg, guidance_scale), latents)
+            else:                                                                                   # :1035-1054
+                latents = self._step_with(self.scheduler_main, eps, latents, t, unet_batch, do_cfg, guidance_scale,
+                                          eta, generator, x0_preds)
+                if _is_dpm(self.scheduler_inter):
+                    _push_history(self.scheduler_inter, self._combined(eps, do_cfg, guidance_scale), latents)
+        torch.cuda.synchronize(device)
+        return self._finish(latents, x0_preds, output_type, return_dict, time.time() - start_time)
+
+
+@models_registry.add_to_registry("stable_diffusion_model_skip_timesteps")
+class StableDiffusionModelSkipTimesteps(_VariantBase):
+    """``src/models.py:1138-1467``: the plain loop with the loop indices in ``skip_timesteps`` skipped
+    (``:1327-1330``).  A multistep scheduler's internal step index is not advanced for a skipped step -- the
+    reference's behaviour, kept."""
+
+    @torch.no_grad()
+    def call(self, prompt=None, height=None, width=None, num_inference_steps: int = 50, skip_timesteps=None,
+             timesteps=None, sigmas=None, guidance_scale: float = 7.5, negative_prompt=None,
+             num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+             negative_prompt_embeds=None, output_type: str = "pil", return_dict: bool = True,
+             guidance_rescale: float = 0.0, **kwargs):
+        skip = set(int(i) for i in (skip_timesteps or []))
+        device, batch_size, do_cfg, ctx = self._begin(prompt, height, width, guidance_scale, negative_prompt,
+                                                      num_images_per_prompt, prompt_embeds, negative_prompt_embeds,
+                                                      guidance_rescale, timesteps, sigmas)
+        c = self.unet_config
+        unet_batch = ctx.shape[0]
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        ts_host = list(self.scheduler._timesteps_list)
+        latents = self.prepare_latents(batch_size, c.in_channels, c.sample_size * 8, c.sample_size * 8, device,
+                                       generator, latents)
+        self.unet.set_deepcache(-1)
+        self.unet.set_context(ctx)
+        eps = self._eps_buffer(unet_batch, device)
+        self._num_timesteps = len(ts_host)                                                          # :1322
+        x0_preds = []
+        torch.cuda.synchronize(device)
+        start_time = time.time()
+        for i, t in enumerate(ts_host):
+            if i in skip:                                                                           # :1327-1330
+                continue
+            latents = self._step_with(self.scheduler, eps, latents, t, unet_batch, do_cfg, guidance_scale, eta,
+                                      generator, x0_preds)
+        torch.cuda.synchronize(device)
+        return self._finish(latents, x0_preds, output_type, return_dict, time.time() - start_time)
 
 
 def _fuse_synthetic_lora(sd, seed: int, scale: float, rank: int):

@@ -223,11 +223,17 @@ class DPMSolverScheduler(_FusedStepScheduler):
         self.lower_order_nums = 0
         self.sigmas: Optional[np.ndarray] = None
 
-    def set_timesteps(self, num_inference_steps: int, device=None):
+    def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None, timesteps=None):
+        """``timesteps``: custom schedule, as diffusers 0.32.1 accepts it and the two-scheduler pipeline uses it
+        (``src/models.py:488-492``)."""
         c = self.config
         T = c.num_train_timesteps
         last = T
-        if c.timestep_spacing == "linspace":
+        if num_inference_steps is None and timesteps is None:
+            raise ValueError("Must pass exactly one of `num_inference_steps` or `timesteps`.")
+        if timesteps is not None:
+            ts = np.array([int(t) for t in timesteps]).astype(np.int64)
+        elif c.timestep_spacing == "linspace":
             ts = np.linspace(0, last - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
         elif c.timestep_spacing == "leading":
             ratio = last // (num_inference_steps + 1)

@@ -246,3 +246,59 @@ def test_synthetic_weights_are_seeded_and_on_bf16_grid():
     w = a["down_blocks.0.resnets.0.conv1.weight"]
     assert torch.equal(w, w.to(torch.bfloat16).float())
     assert abs(float(a["conv_norm_out.weight"].mean()) - 1.0) < 0.1
+
+
+# ---------------------------------------------------------------- variant pipelines, host logic
+def test_variant_registry_keys():
+    from sonicdiffusionbayeslab_amd.registry import methods_registry, models_registry
+    for k in ("stable_diffusion_model_two_schedulers", "stable_diffusion_model_interliving_schedulers",
+              "stable_diffusion_model_skip_timesteps"):
+        assert models_registry[k] is not None
+    for k in ("two_schedulers", "interliving_schedulers", "skip_steps"):
+        assert methods_registry[k] is not None
+
+
+def test_switch_timestamp_matches_oracle_and_reference_rules():
+    """src/models.py:704-730 on the DDIM(10) schedule handed to DPM as custom timesteps."""
+    from oracle.pipeline import switch_timestamp as o_switch
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModelTwoSchedulers as M
+    first = [901, 801, 701, 601, 501, 401, 301, 201, 101, 1]
+    second = [950, 850, 710, 690, 500, 300, 100]
+    for kind, want in (("closest", [710, 690, 500, 300, 100]),          # |710-701| = 9 is the minimum
+                       ("left_closest", [710, 690, 500, 300, 100]),      # last entry >= 701
+                       ("right_closest", [690, 500, 300, 100])):         # first entry <= 701
+        f, s = M.switch_timestamp(first, second, 3, kind)
+        assert f == [901, 801, 701] and s == want, (kind, s)
+        assert (f, s) == o_switch(first, second, 3, kind)
+    # identical schedules (what the pipeline really passes): the switch timestep is taken twice, once by each scheduler
+    f, s = M.switch_timestamp(first, first, 4, "closest")
+    assert f == first[:4] and s == first[3:]
+
+
+def test_interleave_plan_matches_oracle():
+    """src/models.py:952-966: groups of `solver_order` main steps -> one inter step at the group's first timestep."""
+    from oracle.pipeline import interleave_plan as o_plan
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModelInterlivingSchedulers as M
+    ts = list(range(900, 0, -100))          # 9 steps
+    keep, t_inter = M.interleave_plan(ts, 2, [1, 3])
+    assert keep == [900, 800, 700, 500, 400, 300, 100] and t_inter == [700, 300]
+    assert (keep, t_inter) == o_plan(ts, 2, [1, 3])
+    keep, t_inter = M.interleave_plan(ts, 3, [0])
+    assert keep == [900, 600, 500, 400, 300, 200, 100] and t_inter == [900]
+
+
+def test_dpm_custom_timesteps_match_oracle():
+    """set_timesteps(timesteps=...) (two-scheduler pipeline, src/models.py:488-492): same sigma table as the oracle."""
+    import numpy as np
+    from oracle.schedulers import DDIMOracle, DPMSolverOracle
+    from sonicdiffusionbayeslab_amd.schedulers import DDIMSchedulerMy, DPMSolverScheduler, PNDMConfigStub
+    kw = dict(solver_order=2, algorithm_type="dpmsolver++", final_sigmas_type="zero")
+    d = DDIMSchedulerMy.from_config(PNDMConfigStub().config); d.set_timesteps(10)
+    s = DPMSolverScheduler.from_config(PNDMConfigStub().config, **kw); s.set_timesteps(timesteps=d._timesteps_list)
+    od = DDIMOracle(); od.set_timesteps(10)
+    o = DPMSolverOracle(**kw); o.set_timesteps(timesteps=[int(t) for t in od.timesteps])
+    assert s._timesteps_list == [int(t) for t in o.timesteps] == d._timesteps_list
+    assert s.num_inference_steps == 10 and len(s.sigmas) == 11
+    np.testing.assert_allclose(np.asarray(s.sigmas), o.sigmas.numpy(), rtol=1e-6)
+    with pytest.raises(ValueError):
+        s.set_timesteps()
