@@ -90,6 +90,28 @@ int sd_vae_create(const sd_unet_config* cfg, sd_vae** out);
 int sd_vae_decode(sd_vae* v, void* stream, const float* latents, int batch, float latent_scale, float* images_out,
                   void* workspace, long long workspace_bytes);
 
+/* ---- CLIP text encoder: replaces `self.text_encoder(text_input_ids)[0]` inside
+ * `encode_prompt` (src/models.py:139-155; transformers CLIPTextModel, quick_gelu, causal mask).  `sd_clip` IS the
+ * `sd_unet` handle type: parameters (transformers names, `text_model.` prefix: embeddings.token_embedding.weight,
+ * encoder.layers.N.self_attn.{q,k,v,out}_proj.*, layer_norm1/2.*, mlp.fc1/fc2.*, final_layer_norm.*) are
+ * enumerated / loaded / finalised and the workspace is sized (unet_batch = prompts, cache_branch_id = -1) through the
+ * sd_unet_* functions.  encode: device int32 token ids [batch, max_positions] -> device fp32
+ * last_hidden_state [batch, max_positions, hidden_size] (what `prompt_embeds` is, src/models.py:139-150).
+ * Tokenisation (CLIP BPE) is host-side text processing and stays in the host language. */
+typedef struct sd_clip_config {
+    int vocab_size;          /* 49408 */
+    int hidden_size;         /* 768 */
+    int num_layers;          /* 12 */
+    int num_heads;           /* 12 */
+    int intermediate_size;   /* 3072 */
+    int max_positions;       /* 77 */
+    float layer_norm_eps;    /* 1e-5 */
+} sd_clip_config;
+typedef struct sd_unet sd_clip;
+int sd_clip_create(const sd_clip_config* cfg, sd_clip** out);
+int sd_clip_encode(sd_clip* c, void* stream, const int* input_ids, int batch, float* hidden_out, void* workspace,
+                   long long workspace_bytes);
+
 /* Measurement hook for bench.py: the same forward with a hipEvent pair around every launch.  Per
  * op kind (0 sinusoid, 1 gemv, 2 conv_in, 3 groupnorm, 4 conv3x3, 5 gemm, 6 layernorm,
  * 7 attention, 8 conv_out) it returns summed milliseconds, launch count, algorithmic FLOPs and

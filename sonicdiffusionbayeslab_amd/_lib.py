@@ -26,6 +26,13 @@ class SdUnetConfig(C.Structure):
     ]
 
 
+class SdClipConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int), ("hidden_size", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int),
+        ("intermediate_size", C.c_int), ("max_positions", C.c_int), ("layer_norm_eps", C.c_float),
+    ]
+
+
 class SdHipError(RuntimeError):
     pass
 
@@ -54,6 +61,8 @@ _SIGS = {
                                       C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sd_vae_create": (_i, [C.POINTER(SdUnetConfig), C.POINTER(_vp)]),
     "sd_vae_decode": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _ll]),
+    "sd_clip_create": (_i, [C.POINTER(SdClipConfig), C.POINTER(_vp)]),
+    "sd_clip_encode": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _ll]),
     "sd_unet_debug_tensor": (_i, [_vp, _vp, C.c_char_p, _vp, _ll, _vp, _i, _i]),
     "sd_sched_step": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _ll]),
     "sd_op_gemm": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i]),

@@ -78,6 +78,12 @@ int sd_launch_gemv(const float* x, const bf16_t* W, const float* b, float* y, in
                    hipStream_t stream);
 int sd_launch_timestep_sinusoid(float t, float* out, int dim, hipStream_t stream);
 int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
+// clip.hip: CLIP text encoder pieces
+int sd_launch_clip_embed(const int* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* out, int rows, int L, int H,
+                         int vocab, hipStream_t stream);
+int sd_launch_clip_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int H, int heads, hipStream_t stream);
+int sd_launch_quick_gelu(bf16_t* x, long n, hipStream_t stream);
+int sd_launch_bf16_to_f32(const bf16_t* src, float* dst, long n, hipStream_t stream);
 
 // conv_in: NCHW fp32 latents [Bsrc,4,H,W] (batch index taken modulo Bsrc: CFG duplication is
 // fused) -> NHWC bf16 [B,H,W,Cout]

@@ -82,7 +82,8 @@ struct Wrap {  // one DeepCache-wrapped module enclosing an op
     int block_i, layer_i;
 };
 
-enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT, OP_SOFTMAX, OP_PQCONV };
+enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT, OP_SOFTMAX, OP_PQCONV,
+              OP_CLIP_EMBED, OP_CLIP_ATTN, OP_QGELU, OP_TO_F32 };
 
 struct Op {
     int kind = 0;
@@ -129,8 +130,9 @@ struct Plan {
 }  // namespace
 
 struct sd_unet {
-    int kind = 0;   // 0 = UNet2DConditionModel, 1 = AutoencoderKL decoder (sd_vae is the same handle type)
+    int kind = 0;   // 0 = UNet2DConditionModel, 1 = AutoencoderKL decoder, 2 = CLIP text encoder (same handle type)
     sd_unet_config cfg;
+    sd_clip_config clip;
     std::vector<ParamSpec> params;
     std::unordered_map<std::string, int> pindex;
     std::unordered_map<std::string, size_t> woff;  // packed item -> byte offset into dweights
@@ -254,6 +256,30 @@ void enumerate_params(sd_unet* u) {
 }
 
 // AutoencoderKL decoder (diffusers names): post_quant_conv + decoder.*  
+// transformers CLIPTextModel state_dict names (4.48.0 layout, `text_model.` prefix)
+std::string clip_layer(int i) { return "text_model.encoder.layers." + std::to_string(i) + "."; }
+
+void enumerate_params_clip(sd_unet* u) {
+    const sd_clip_config& c = u->clip;
+    Enum e{u};
+    const int H = c.hidden_size, I = c.intermediate_size;
+    e.add("text_model.embeddings.token_embedding.weight", {c.vocab_size, H});
+    e.add("text_model.embeddings.position_embedding.weight", {c.max_positions, H});
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string p = clip_layer(i);
+        for (const char* n : {"k_proj", "v_proj", "q_proj", "out_proj"}) {
+            e.add(p + "self_attn." + n + ".weight", {H, H});
+            e.add(p + "self_attn." + n + ".bias", {H});
+        }
+        e.add(p + "layer_norm1.weight", {H}); e.add(p + "layer_norm1.bias", {H});
+        e.add(p + "mlp.fc1.weight", {I, H}); e.add(p + "mlp.fc1.bias", {I});
+        e.add(p + "mlp.fc2.weight", {H, I}); e.add(p + "mlp.fc2.bias", {H});
+        e.add(p + "layer_norm2.weight", {H}); e.add(p + "layer_norm2.bias", {H});
+    }
+    e.add("text_model.final_layer_norm.weight", {H});
+    e.add("text_model.final_layer_norm.bias", {H});
+}
+
 void enumerate_params_vae(sd_unet* u) {
     const sd_unet_config& c = u->cfg;
     Enum e{u};
@@ -466,8 +492,33 @@ int pack_vae(sd_unet* u) {
     return 0;
 }
 
+int pack_clip(sd_unet* u) {
+    const sd_clip_config& c = u->clip;
+    Packer pk{u};
+    pk.bf16_same("text_model.embeddings.token_embedding.weight");
+    pk.bf16_same("text_model.embeddings.position_embedding.weight");
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string p = clip_layer(i), a = p + "self_attn.";
+        pk.concat_rows(a + "qkv.weight", {a + "q_proj.weight", a + "k_proj.weight", a + "v_proj.weight"});
+        {
+            size_t off = pk.alloc(a + "qkv.bias", (size_t)3 * c.hidden_size * 4);
+            float* o = (float*)(u->hblob.data() + off);
+            for (const char* n : {"q_proj.bias", "k_proj.bias", "v_proj.bias"})
+                for (float v : pk.P(a + n)) *o++ = v;
+        }
+        pk.bf16_same(a + "out_proj.weight"); pk.f32(a + "out_proj.bias");
+        pk.f32(p + "layer_norm1.weight"); pk.f32(p + "layer_norm1.bias");
+        pk.bf16_same(p + "mlp.fc1.weight"); pk.f32(p + "mlp.fc1.bias");
+        pk.bf16_same(p + "mlp.fc2.weight"); pk.f32(p + "mlp.fc2.bias");
+        pk.f32(p + "layer_norm2.weight"); pk.f32(p + "layer_norm2.bias");
+    }
+    pk.f32("text_model.final_layer_norm.weight"); pk.f32("text_model.final_layer_norm.bias");
+    return 0;
+}
+
 int pack_all(sd_unet* u) {
     if (u->kind == 1) return pack_vae(u);
+    if (u->kind == 2) return pack_clip(u);
     const sd_unet_config& c = u->cfg;
     Packer pk{u};
     const int c0 = c.block_out_channels[0], temb = 4 * c0, nl = c.num_levels;
@@ -698,8 +749,36 @@ struct Builder {
           o.w = W("decoder.conv_out.weight"); o.b = W("decoder.conv_out.bias"); push(o); }
     }
 
+    // CLIPTextTransformer (transformers 4.48.0 modeling_clip.py): token + position embedding,
+    // pre-LN layers with causal self-attention and a quick_gelu MLP, final LayerNorm -> last_hidden_state
+    void build_clip() {
+        const sd_clip_config& c = u->clip;
+        const int L = c.max_positions, H = c.hidden_size, I = c.intermediate_size, M = UB * L;
+        int t;
+        { Op o; o.kind = OP_CLIP_EMBED; o.x1 = T_LATENTS; o.M = M; o.N = H; o.Nk = L;
+          o.w = W("text_model.embeddings.token_embedding.weight"); o.g = W("text_model.embeddings.position_embedding.weight");
+          o.out = tensor((size_t)M * H * 2); push(o); t = o.out; }
+        for (int i = 0; i < c.num_layers; ++i) {
+            const std::string p = clip_layer(i), a = p + "self_attn.";
+            int n1 = ln(t, M, H, p + "layer_norm1.weight", p + "layer_norm1.bias");
+            int qkv = gemm(n1, H, -1, 0, M, 3 * H, a + "qkv.weight", a + "qkv.bias", -1, 0);
+            int at;
+            { Op o; o.kind = OP_CLIP_ATTN; o.x1 = qkv; o.B = UB; o.Nq = L; o.N = H; o.heads = c.num_heads;
+              o.out = tensor((size_t)M * H * 2); push(o); at = o.out; }
+            t = gemm(at, H, -1, 0, M, H, a + "out_proj.weight", a + "out_proj.bias", t, 0);
+            int n2 = ln(t, M, H, p + "layer_norm2.weight", p + "layer_norm2.bias");
+            int f = gemm(n2, H, -1, 0, M, I, p + "mlp.fc1.weight", p + "mlp.fc1.bias", -1, 0);
+            { Op o; o.kind = OP_QGELU; o.x1 = f; o.out = f; o.M = M; o.N = I; push(o); }
+            t = gemm(f, I, -1, 0, M, H, p + "mlp.fc2.weight", p + "mlp.fc2.bias", t, 0);
+            pl.taps["layer" + std::to_string(i)] = t;
+        }
+        int f = ln(t, M, H, "text_model.final_layer_norm.weight", "text_model.final_layer_norm.bias");
+        { Op o; o.kind = OP_TO_F32; o.x1 = f; o.out = T_EPS; o.M = M; o.N = H; push(o); }
+    }
+
     void build() {
         if (u->kind == 1) { build_vae(); return; }
+        if (u->kind == 2) { build_clip(); return; }
         const sd_unet_config& c = u->cfg;
         const int nl = c.num_levels, c0 = c.block_out_channels[0], temb = 4 * c0;
         const int L = c.context_len;
@@ -942,6 +1021,15 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.consts = g_zero_page;
             return sd_launch_attention(a, stream);
         }
+        case OP_CLIP_EMBED:
+            return sd_launch_clip_embed((const int*)latents, (const bf16_t*)(wb + o.w), (const bf16_t*)(wb + o.g),
+                                        (bf16_t*)T(o.out), o.M, o.Nk, o.N, u->clip.vocab_size, stream);
+        case OP_CLIP_ATTN:
+            return sd_launch_clip_attention((const bf16_t*)T(o.x1), (bf16_t*)T(o.out), o.B, o.Nq, o.N, o.heads, stream);
+        case OP_QGELU:
+            return sd_launch_quick_gelu((bf16_t*)T(o.x1), (long)o.M * o.N, stream);
+        case OP_TO_F32:
+            return sd_launch_bf16_to_f32((const bf16_t*)T(o.x1), eps_out, (long)o.M * o.N, stream);
         case OP_CONV_OUT:
             return sd_launch_conv_out((const bf16_t*)T(o.x1), (const bf16_t*)(wb + o.w), (const float*)(wb + o.b), eps_out,
                                       o.B, o.Hin, o.Win, o.Cin, o.N, stream);
@@ -1015,6 +1103,44 @@ extern "C" int sd_vae_decode(sd_unet* u, void* stream, const float* latents, int
     SD_REQUIRE(((uintptr_t)workspace & 255) == 0, "vae_decode: workspace must be 256-byte aligned");
     for (size_t i = 0; i < pl->ops.size(); ++i)
         if ((rc = run_op(u, *pl, pl->ops[i], (char*)workspace, latents, batch, images_out, latent_scale, (hipStream_t)stream)))
+            return rc;
+    return 0;
+}
+
+// ---- CLIP text encoder: `self.text_encoder(text_input_ids)[0]` inside encode_prompt (src/models.py:139-155) ----
+extern "C" int sd_clip_create(const sd_clip_config* cfg, sd_unet** out) {
+    SD_REQUIRE(cfg && out, "sd_clip_create: null argument");
+    SD_REQUIRE(cfg->hidden_size % 64 == 0 && cfg->intermediate_size % 64 == 0,
+               "sd_clip_create: hidden %d / intermediate %d must be multiples of 64", cfg->hidden_size, cfg->intermediate_size);
+    SD_REQUIRE(cfg->hidden_size <= 1536, "sd_clip_create: hidden size %d (LayerNorm kernel handles <= 1536)", cfg->hidden_size);
+    SD_REQUIRE(cfg->num_heads > 0 && cfg->hidden_size % cfg->num_heads == 0, "sd_clip_create: heads");
+    const int d = cfg->hidden_size / cfg->num_heads;
+    SD_REQUIRE(d == 64 || d == 16, "sd_clip_create: head dim %d (64 and 16 are built)", d);
+    SD_REQUIRE(cfg->max_positions >= 1 && cfg->max_positions <= 128, "sd_clip_create: max_positions %d", cfg->max_positions);
+    SD_REQUIRE(cfg->vocab_size >= 1 && cfg->num_layers >= 1, "sd_clip_create: vocab/layers");
+    SD_REQUIRE(fabsf(cfg->layer_norm_eps - 1e-5f) < 1e-9f, "sd_clip_create: layer_norm_eps %g (1e-5 is built)", cfg->layer_norm_eps);
+    sd_unet* u = new sd_unet();
+    u->kind = 2;
+    memset(&u->cfg, 0, sizeof(u->cfg));
+    u->cfg.num_levels = 1;
+    u->clip = *cfg;
+    enumerate_params_clip(u);
+    *out = u;
+    return 0;
+}
+
+extern "C" int sd_clip_encode(sd_unet* u, void* stream, const int* input_ids, int batch, float* hidden_out,
+                              void* workspace, long long workspace_bytes) {
+    SD_REQUIRE(u && u->kind == 2, "clip_encode: not a CLIP handle");
+    SD_REQUIRE(input_ids && hidden_out && workspace && batch > 0, "clip_encode: null argument");
+    Plan* pl;
+    int rc = get_plan(u, batch, -1, &pl);
+    if (rc) return rc;
+    SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "clip_encode: workspace too small (%lld < %zu)", workspace_bytes,
+               pl->total_bytes);
+    SD_REQUIRE(((uintptr_t)workspace & 255) == 0, "clip_encode: workspace must be 256-byte aligned");
+    for (size_t i = 0; i < pl->ops.size(); ++i)
+        if ((rc = run_op(u, *pl, pl->ops[i], (char*)workspace, (const float*)input_ids, batch, hidden_out, 0.f, (hipStream_t)stream)))
             return rc;
     return 0;
 }

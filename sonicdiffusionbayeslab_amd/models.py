@@ -15,9 +15,10 @@ brackets it with device synchronisation so the number is real.
 ``output_type="pt"`` decodes through the libsdhip AutoencoderKL decoder (``vae.py``, SURVEY 8f row 1;
 outside the timed loop, as in the reference).  The three variant pipelines of ``src/models.py:338-1467``
 (two schedulers, interleaved schedulers, skipped timesteps) are host-only control flow over
-the same kernels and live at the bottom of this file.  Still out of scope: the CLIP text
-encoder -- prompts are encoded by a pluggable ``text_encoder`` (default: a deterministic seeded
-stand-in, since no CLIP weights exist offline).
+the same kernels and live at the bottom of this file.  Prompts are encoded by a pluggable ``text_encoder``:
+the CLIP text tower on libsdhip + BPE tokenizer (``clip.py``) when the checkpoint directory
+carries ``tokenizer/`` and ``text_encoder/``, otherwise a deterministic seeded stand-in (no CLIP weights
+exist offline) -- ``weights_source`` / the reports say which.
 """
 from __future__ import annotations
 
@@ -72,7 +73,7 @@ class StableDiffusionModel:
 
     def __init__(self, unet_config: Optional[UNetConfig] = None, state_dict=None, scheduler=None,
                  text_encoder: Optional[Callable] = None, vae_decoder: Optional[Callable] = None,
-                 weights_seed: int = 1234, source: str = "synthetic"):
+                 weights_seed: int = 1234, source: str = "synthetic", clip_dir: Optional[str] = None):
         self.unet_config = unet_config or UNetConfig()
         self._state_dict = state_dict
         self._weights_seed = weights_seed
@@ -81,6 +82,8 @@ class StableDiffusionModel:
         self.scheduler = scheduler or PNDMConfigStub()
         self.text_encoder = text_encoder or SyntheticTextEncoder(self.unet_config.context_len,
                                                                  self.unet_config.cross_attention_dim)
+        # a local checkpoint with tokenizer/ + text_encoder/: the CLIP text tower on libsdhip replaces the stand-in
+        self._clip_dir = clip_dir if text_encoder is None else None
         self.vae_decoder = vae_decoder
         self.vae_config = _VaeConfig()
         self.device = torch.device("cpu")
@@ -100,7 +103,11 @@ class StableDiffusionModel:
         by ``SD_AMD_WEIGHTS_SEED`` (default 1234) are used and ``weights_source`` says so."""
         path = os.environ.get("SD_AMD_MODEL_DIR") or str(pretrained_model_name_or_path)
         if os.path.isdir(path):
-            return cls(state_dict=load_unet_state_dict(path), source=f"local:{path}", **kwargs)
+            has_clip = all(os.path.exists(os.path.join(path, *p)) for p in (("tokenizer", "vocab.json"),
+                                                                            ("tokenizer", "merges.txt"),
+                                                                            ("text_encoder", "model.safetensors")))
+            return cls(state_dict=load_unet_state_dict(path), source=f"local:{path}",
+                       clip_dir=path if has_clip else None, **kwargs)
         seed = int(os.environ.get("SD_AMD_WEIGHTS_SEED", "1234"))
         return cls(weights_seed=seed, source=f"synthetic(seed={seed}) for {pretrained_model_name_or_path}", **kwargs)
 
@@ -134,6 +141,10 @@ class StableDiffusionModel:
         if device.type == "cuda":
             self._ensure_unet()
             self.device = self.unet.device
+            if self._clip_dir is not None:
+                from .clip import ClipPromptEncoder
+                self.text_encoder = ClipPromptEncoder.from_pretrained(self._clip_dir, device=str(self.device))
+                self._clip_dir = None
         return self
 
     # LCM-LoRA hooks used by src/experiments/consistency_model.py:20-21
