@@ -114,8 +114,12 @@ class StableDiffusionModel:
     def _ensure_unet(self):
         if self.unet is None:
             sd = self._state_dict or make_synthetic_state_dict(self.unet_config, self._weights_seed)
-            for (seed, scale, rank) in self._lora:
-                _fuse_synthetic_lora(sd, seed, scale, rank)
+            for item in self._lora:
+                if item[0] == "file":
+                    from .weights import fuse_lora_state_dict
+                    fuse_lora_state_dict(sd, item[1], item[2])
+                else:
+                    _fuse_synthetic_lora(sd, *item)
             self.unet = HipUNet2DConditionModel(self.unet_config, sd, device="cuda:%d" % torch.cuda.current_device())
             self._state_dict = None
 
@@ -149,8 +153,18 @@ class StableDiffusionModel:
 
     # LCM-LoRA hooks used by src/experiments/consistency_model.py:20-21
     def load_lora_weights(self, adapter_id, scale: float = 1.0, rank: int = 64):
+        """A local LoRA file / directory (``pytorch_lora_weights.safetensors``) is read and fused for real
+        (``weights.fuse_lora_state_dict``); a hub NAME is a network fetch, for which a seeded synthetic
+        low-rank update of the same structure stands in."""
         if self.unet is not None:
             raise RuntimeError("load_lora_weights must be called before the model is moved to the GPU")
+        path = str(adapter_id)
+        if os.path.isdir(path):
+            path = os.path.join(path, "pytorch_lora_weights.safetensors")
+        if os.path.isfile(path):
+            from safetensors.torch import load_file
+            self._pending_lora = ("file", load_file(path), scale)
+            return
         seed = int.from_bytes(hashlib.sha256(str(adapter_id).encode()).digest()[:4], "little")
         self._pending_lora = (seed, scale, rank)
 

@@ -136,3 +136,51 @@ def load_unet_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
     raise FileNotFoundError(
         f"no local UNet weights under {model_dir!r}; model names are network fetches and are "
         "unavailable offline -- use synthetic weights or point at a local diffusers directory")
+
+
+def fuse_lora_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], scale: float = 1.0) -> int:
+    """``pipe.load_lora_weights(...); pipe.fuse_lora()`` on the host copy of the UNet weights
+    (``src/experiments/consistency_model.py:20-21``): ``W += scale * (alpha / r) * up @ down`` for every adapted
+    module, linear or conv (3x3 ``down`` [r,I,kh,kw] with 1x1 ``up`` [O,r,1,1]).  Accepts the two layouts LoRA
+    files for SD-1.5 come in [upstream-recall]: kohya (``lora_unet_<module with _>.lora_down/.lora_up.weight`` +
+    ``.alpha``, what ``latent-consistency/lcm-lora-sdv1-5`` ships) and peft/diffusers
+    (``unet.<module>.lora_A/.lora_B.weight``, alpha = r).  Text-encoder entries are ignored.  Returns the number of
+    fused modules; raises if an adapted UNet module does not exist."""
+    flat = {k[: -len(".weight")].replace(".", "_"): k for k in sd if k.endswith(".weight")}
+    pairs = {}
+    for k, v in lora_sd.items():
+        if k.startswith("lora_te") or k.startswith("text_encoder."):
+            continue
+        if k.startswith("lora_unet_"):
+            mod, _, leaf = k[len("lora_unet_"):].partition(".")
+            target = flat.get(mod)
+            if target is None:
+                raise KeyError(f"LoRA module {mod!r} has no counterpart in the UNet")
+            slot = {"lora_down.weight": "down", "lora_up.weight": "up", "alpha": "alpha"}.get(leaf)
+        elif k.startswith("unet."):
+            body = k[len("unet."):]
+            for tag, slot_ in ((".lora_A.weight", "down"), (".lora_B.weight", "up"), (".lora.down.weight", "down"),
+                               (".lora.up.weight", "up")):
+                if body.endswith(tag):
+                    target, slot = body[: -len(tag)] + ".weight", slot_
+                    break
+            else:
+                continue
+            if target not in sd:
+                raise KeyError(f"LoRA module {target!r} has no counterpart in the UNet")
+        else:
+            continue
+        if slot is not None:
+            pairs.setdefault(target, {})[slot] = v
+    n = 0
+    for target, p in pairs.items():
+        if "down" not in p or "up" not in p:
+            raise KeyError(f"incomplete LoRA pair for {target}")
+        down, up = p["down"].float(), p["up"].float()
+        r = down.shape[0]
+        alpha = float(p["alpha"]) if "alpha" in p else float(r)
+        w = sd[target]
+        delta = (up.reshape(up.shape[0], r) @ down.reshape(r, -1)).reshape(w.shape)
+        sd[target] = (w.float() + scale * (alpha / r) * delta).to(torch.bfloat16).float()
+        n += 1
+    return n

@@ -302,3 +302,31 @@ def test_dpm_custom_timesteps_match_oracle():
     np.testing.assert_allclose(np.asarray(s.sigmas), o.sigmas.numpy(), rtol=1e-6)
     with pytest.raises(ValueError):
         s.set_timesteps()
+
+
+def test_fuse_lora_state_dict_kohya_and_peft_layouts():
+    """load_lora_weights + fuse_lora (src/experiments/consistency_model.py:20-21) on the host weights."""
+    from sonicdiffusionbayeslab_amd.weights import fuse_lora_state_dict
+    g = torch.Generator().manual_seed(3)
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    lin, conv = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q", "down_blocks.0.resnets.0.conv1"
+    base = {lin + ".weight": r16(torch.randn(64, 64, generator=g)), conv + ".weight": r16(torch.randn(64, 64, 3, 3, generator=g)),
+            conv + ".bias": torch.zeros(64)}
+    dl, ul = torch.randn(4, 64, generator=g), torch.randn(64, 4, generator=g)
+    dc, uc = torch.randn(4, 64, 3, 3, generator=g), torch.randn(64, 4, 1, 1, generator=g)
+    want_lin = r16(base[lin + ".weight"] + 0.5 * (8.0 / 4) * ul @ dl)
+    want_conv = r16(base[conv + ".weight"] + 0.5 * (8.0 / 4) * torch.einsum("or,rikl->oikl", uc[:, :, 0, 0], dc))
+    kohya = {"lora_unet_" + lin.replace(".", "_") + ".lora_down.weight": dl, "lora_unet_" + lin.replace(".", "_") + ".lora_up.weight": ul,
+             "lora_unet_" + lin.replace(".", "_") + ".alpha": torch.tensor(8.0),
+             "lora_unet_" + conv.replace(".", "_") + ".lora_down.weight": dc, "lora_unet_" + conv.replace(".", "_") + ".lora_up.weight": uc,
+             "lora_unet_" + conv.replace(".", "_") + ".alpha": torch.tensor(8.0),
+             "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight": torch.zeros(4, 8)}
+    sd = dict(base)
+    assert fuse_lora_state_dict(sd, kohya, scale=0.5) == 2
+    assert torch.equal(sd[lin + ".weight"], want_lin) and torch.equal(sd[conv + ".weight"], want_conv)
+    peft = {"unet." + lin + ".lora_A.weight": dl, "unet." + lin + ".lora_B.weight": ul}          # alpha = r
+    sd = dict(base)
+    assert fuse_lora_state_dict(sd, peft, scale=1.0) == 1
+    assert torch.equal(sd[lin + ".weight"], r16(base[lin + ".weight"] + ul @ dl))
+    with pytest.raises(KeyError):
+        fuse_lora_state_dict(dict(base), {"lora_unet_no_such_module.lora_down.weight": dl}, 1.0)
