@@ -23,7 +23,13 @@ def init_process_group(backend: str = "nccl") -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.device_count() > 0:
+            # bind the rank to its GPU BEFORE the RCCL communicator exists (one process per GPU)
+            dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
