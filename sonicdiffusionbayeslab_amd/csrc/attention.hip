@@ -502,6 +502,307 @@ __global__ __launch_bounds__(DmaCfg<D>::NW * 64, D == 40 ? 4 : 3) void attn_dma_
     }
 }
 
+// =====================================================================================================
+// Software-pipelined variant for D = 40 and key counts that are a multiple of 64 (the 64x64 self-attention).
+// The plain loop above is a serial chain per tile -- QK^T MFMAs, softmax VALU, PV MFMAs -- and on gfx950 the
+// matrix and vector pipes of a SIMD barely overlap ACROSS waves (measured: their busy times add up to the
+// kernel time), but they do overlap when one wave's instruction stream interleaves them (probe: valu 750 +
+// mfma 455 -> 900 cycles).  So each iteration here carries two independent strands:
+//     phase A:  exp2/pack of S(t)                 ||  S(t+1) = K(t+1) . Q^T      (6 MFMAs)
+//     phase B:  max over S(t+1), new running max  ||  O^T += V(t)^T . P(t)^T     (8 MFMAs)
+// and the rare O rescale is applied after PV(t).  Ring of 4 LDS tiles: tiles t (V) and t+1 (K) are in use,
+// t+2 and t+3 are in flight.  4 waves per workgroup (one per SIMD), 128 queries.
+// =====================================================================================================
+struct PipeCfg {
+    static constexpr int D = 40, KQ = 3, DVT = 2, CD = 5, CHK = 5, CHV = 6, RSK = 80, RSV = 96;
+    static constexpr int KBYTES = 64 * RSK, NI = CHK + CHV, NW = 4;
+    static constexpr int NIW = 3;                      // DMA pieces per wave and tile: 11 real + 1 padding piece
+    static constexpr int TILE = NIW * NW * 1024;       // 12 KiB slot: K rows, V rows, 1 KiB the padding piece lands in
+    static constexpr int NSLOT = 4, SMEM = TILE * NSLOT;
+    static_assert(TILE >= 64 * (RSK + RSV) + 256, "slot holds the tile + the tr over-read of the last V row");
+};
+
+__global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const AttnArgs a) {
+    using Cfg = PipeCfg;
+    constexpr int D = Cfg::D, KQ = Cfg::KQ, DVT = Cfg::DVT, CD = Cfg::CD, CHK = Cfg::CHK, CHV = Cfg::CHV;
+    constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, KBYTES = Cfg::KBYTES, TILE = Cfg::TILE, NI = Cfg::NI, NIW = Cfg::NIW;
+    constexpr int NW = Cfg::NW;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q = blockIdx.x * (NW * 32) + wave * 32 + r;
+    const bool qvalid = q < a.Nq;
+    const float c = a.scale * 1.4426950408889634f;
+    const char* zero = (const char*)a.consts;
+    const char* ones = zero + 256;
+
+    bf16x8 qf[KQ];
+    {
+        const bf16_t* qp = a.Q + ((long)b * a.Nq + (qvalid ? q : 0)) * a.ldq + head * D;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int col = kk * 16 + h * 8;
+            if (qvalid && col < D) qf[kk] = *(const bf16x8*)(qp + col);
+            else qf[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(qf[kk]));   // retire the loads before the DMA ring starts
+    }
+
+    // Branch-free LDS-DMA descriptors: per piece a source pointer for tile 0 and a byte step per tile (0 for
+    // the zero / ones chunks and the padding piece).  Every wave issues exactly NIW pieces per tile.
+    const char* d_ptr[NIW];
+    long d_step[NIW];
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int inst = wave + NW * j;
+        d_ptr[j] = zero; d_step[j] = 0;
+        if (inst < CHK) {
+            const int ch = inst * 64 + lane, key = ch / CHK, part = ch - key * CHK;
+            if (part < CD) {
+                d_ptr[j] = (const char*)(a.K + (long)b * a.Nk * a.ldk + head * D + (long)key * a.ldk + part * 8);
+                d_step[j] = 64 * a.ldk * 2;
+            }
+        } else if (inst < NI) {
+            const int ch = (inst - CHK) * 64 + lane, key = ch / CHV, part = ch - key * CHV;
+            if (part < CD) {
+                d_ptr[j] = (const char*)(a.V + (long)b * a.Nk * a.ldv + head * D + (long)key * a.ldv + part * 8);
+                d_step[j] = 64 * a.ldv * 2;
+            } else if (part == CD) {
+                d_ptr[j] = ones;
+            }
+        }
+    }
+    const int ntiles = a.Nk / 64;                 // >= 4, all full (checked by the launcher)
+    auto issue = [&](int t) {                     // tiles past the end fetch the zero page (their slot is free)
+        char* base = smem + (t & 3) * TILE;
+        const bool real = t < ntiles;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const char* src = real ? d_ptr[j] + d_step[j] * t : zero;
+            glds16(src, base + (wave + NW * j) * 1024);
+        }
+    };
+    auto wait_keep = [&](int tiles_in_flight) {   // the newest 0 / 1 / 2 tiles may still be pending
+        if (tiles_in_flight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");
+        else if (tiles_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    f32x16 o[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+
+    const int kfrag_off = pi_swap23(r) * RSK + h * 16;
+    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int vtr_off = KBYTES + (8 * h + q4) * RSV + (16 * g16 + 4 * p4) * 2;
+
+    auto qk = [&](const char* tile, f32x16& s0, f32x16& s1) {
+        const char* kp = tile + kfrag_off;
+        bf16x8 kf[2 * KQ];
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            kf[kk] = *(const bf16x8*)(kp + kk * 32);
+            kf[KQ + kk] = *(const bf16x8*)(kp + 32 * RSK + kk * 32);
+        }
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], f32x16{}, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ], qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+        for (int kk = 1; kk < KQ; ++kk) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + kk], qf[kk], s1, 0, 0, 0);
+        }
+    };
+    auto tile_max = [&](const f32x16& s0, const f32x16& s1) -> float {
+        float tmax = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(s0[i], s1[i]));
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tmax),
+                                                         __builtin_bit_cast(unsigned, tmax), false, false);
+        return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    };
+    auto softmax_p = [&](const f32x16& s0, const f32x16& s1, float mc, bf16x8* pf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sv = s2 < 2 ? s0[8 * s2 + j] : s1[8 * (s2 - 2) + j];
+                p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -mc));
+            }
+            u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+            pf[s2] = __builtin_bit_cast(bf16x8, w);
+        }
+    };
+    auto pv = [&](const char* tile, const bf16x8* pf) {
+#pragma unroll
+        for (int tt = 0; tt < DVT; ++tt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const char* ap = tile + s2 * 16 * RSV + vtr_off + tt * 64;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(ap));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(ap + 4 * RSV));
+                const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[tt], 0, 0, 0);
+            }
+        }
+    };
+
+    issue(0);
+    issue(1);
+    issue(2);
+    wait_keep(2);                                 // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16 sa0, sa1, sb0, sb1;                    // S(t) / S(t+1), roles swap every iteration
+    qk(smem, sa0, sa1);
+    float m_run = tile_max(sa0, sa1);
+
+    // One steady-state iteration (t <= ntiles - 2): consumes S(t) in (c0, c1), produces S(t+1) in (n0, n1).
+    // Hand-interleaved in seven fenced chunks so that every chunk carries matrix AND vector work of one wave:
+    //   chunks 0-2: two QK^T MFMAs of tile t+1  +  exp2/pack of 8 scores of tile t   (P group 0, 1, 2)
+    //   chunk  3  : two PV MFMAs with P group 0 +  exp2/pack of the last 8 scores    (P group 3)
+    //   chunks 4-6: two PV MFMAs with P group 1, 2, 3  +  the running max over S(t+1)
+    auto exp_group = [&](const f32x16& c0, const f32x16& c1, int s2, float mc) -> bf16x8 {
+        float p[8];
+        const f32x2_t cc = {c, c}, mm = {-mc, -mc};
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {          // s*c - m*c two scores at a time: v_pk_fma_f32
+            const f32x2_t sv = s2 < 2 ? f32x2_t{c0[8 * s2 + j], c0[8 * s2 + j + 1]}
+                                      : f32x2_t{c1[8 * (s2 - 2) + j], c1[8 * (s2 - 2) + j + 1]};
+            const f32x2_t e = __builtin_elementwise_fma(sv, cc, mm);
+            p[j] = __builtin_amdgcn_exp2f(e[0]);
+            p[j + 1] = __builtin_amdgcn_exp2f(e[1]);
+        }
+        u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+        return __builtin_bit_cast(bf16x8, w);
+    };
+    auto vfrag = [&](const char* tile, int tt, int s2) -> bf16x8 {
+        const char* ap = tile + s2 * 16 * RSV + vtr_off + tt * 64;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(ap));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(ap + 4 * RSV));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto steady = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        wait_keep(1);                             // tiles t and t+1 landed (t+2 may be in flight)
+        __builtin_amdgcn_s_barrier();             // ... and every wave is past PV(t-1): slot (t+3)&3 is free
+        asm volatile("" ::: "memory");
+        issue(t + 3);
+        const char* cur = smem + (t & 3) * TILE;
+        const char* kp = smem + ((t + 1) & 3) * TILE + kfrag_off;
+        const float mc = m_run * c;
+        bf16x8 kf[2 * KQ];
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            kf[kk] = *(const bf16x8*)(kp + kk * 32);
+            kf[KQ + kk] = *(const bf16x8*)(kp + 32 * RSK + kk * 32);
+        }
+        bf16x8 pf[4], va, vb;
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], f32x16{}, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ], qf[0], f32x16{}, 0, 0, 0);
+        pf[0] = exp_group(c0, c1, 0, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 1], qf[1], n1, 0, 0, 0);
+        pf[1] = exp_group(c0, c1, 1, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[2], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 2], qf[2], n1, 0, 0, 0);
+        pf[2] = exp_group(c0, c1, 2, mc);
+        va = vfrag(cur, 0, 0); vb = vfrag(cur, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[0], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[0], o[1], 0, 0, 0);
+        pf[3] = exp_group(c0, c1, 3, mc);
+        va = vfrag(cur, 0, 1); vb = vfrag(cur, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[1], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[1], o[1], 0, 0, 0);
+        float tm0 = fmaxf(n0[0], n1[0]);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) tm0 = fmaxf(tm0, fmaxf(n0[i], n1[i]));
+        va = vfrag(cur, 0, 2); vb = vfrag(cur, 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[2], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[2], o[1], 0, 0, 0);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) tm0 = fmaxf(tm0, fmaxf(n0[i], n1[i]));
+        va = vfrag(cur, 0, 3); vb = vfrag(cur, 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[3], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[3], o[1], 0, 0, 0);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tm0),
+                                                         __builtin_bit_cast(unsigned, tm0), false, false);
+        const float m_new = fmaxf(m_run, fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int tt = 0; tt < DVT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[tt][i] *= alpha;
+            m_run = m_new;
+        }
+    };
+    auto final_tile = [&](int t, f32x16& c0, f32x16& c1) {
+        wait_keep(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 pf[4];
+        softmax_p(c0, c1, m_run * c, pf);
+        pv(smem + (t & 3) * TILE, pf);
+    };
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+        steady(t, sa0, sa1, sb0, sb1);
+        steady(t + 1, sb0, sb1, sa0, sa1);
+    }
+    if (t + 2 == ntiles) {                        // even tile count: one more steady step, then the last tile
+        steady(t, sa0, sa1, sb0, sb1);
+        final_tile(t + 1, sb0, sb1);
+    } else {
+        final_tile(t, sa0, sa1);
+    }
+
+    // row D of O^T holds sum(P) (ones chunk): tile D/32, row D%32 -> register (RR&3) + 4*(RR>>3), h = 0 half
+    constexpr int TT = D / 32, RR = D % 32, REG = (RR & 3) + 4 * (RR >> 3);
+    const float inv = 1.0f / __shfl(o[TT][REG], r);
+    if (qvalid) {
+        bf16_t* op = a.O + ((long)b * a.Nq + q) * a.ldo + head * D;
+#pragma unroll
+        for (int tt = 0; tt < DVT; ++tt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dv = 32 * tt + 8 * g4 + 4 * h;
+                if (dv < D) {
+                    u32x2 w = {pack2bf(o[tt][4 * g4 + 0] * inv, o[tt][4 * g4 + 1] * inv),
+                               pack2bf(o[tt][4 * g4 + 2] * inv, o[tt][4 * g4 + 3] * inv)};
+                    *(u32x2*)(op + dv) = w;
+                }
+            }
+        }
+    }
+}
+
+int launch_attn_pipe40(const AttnArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe40_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        attr_set = true;
+    }
+    constexpr int QB = PipeCfg::NW * 32;
+    dim3 grid((a.Nq + QB - 1) / QB, a.heads, a.B);
+    hipLaunchKernelGGL(attn_pipe40_kernel, grid, dim3(PipeCfg::NW * 64), PipeCfg::SMEM, stream, a);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int D>
 int launch_attn_dma(const AttnArgs& a, hipStream_t stream) {
     // SD_ATTN_LDS_PAD (KiB): occupancy experiment knob -- extra dynamic LDS limits workgroups per CU
@@ -551,7 +852,11 @@ int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
     static const bool no_dma = getenv("SD_ATTN_NO_DMA") != nullptr;
     const bool dma = !no_dma && a.consts != nullptr;
     switch (a.D) {
-        case 40: return dma ? launch_attn_dma<40>(a, stream) : launch_attn<40>(a, stream);
+        case 40: {
+            static const bool no_pipe = getenv("SD_ATTN_NO_PIPE") != nullptr;
+            if (dma && !no_pipe && a.Nk % 64 == 0 && a.Nk >= 256) return launch_attn_pipe40(a, stream);
+            return dma ? launch_attn_dma<40>(a, stream) : launch_attn<40>(a, stream);
+        }
         case 80: return dma ? launch_attn_dma<80>(a, stream) : launch_attn<80>(a, stream);
         case 160: return launch_attn<160>(a, stream);
         default: sd_set_error("attention: head dim %d not supported (40, 80, 160)", a.D); return -1;
