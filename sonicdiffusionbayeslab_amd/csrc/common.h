@@ -51,6 +51,26 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return x * phi;
 }
 
+// value * GELU(gate) for two lanes of work at once: the polynomial part runs on packed fp32 instructions
+// (v_pk_mul/fma_f32: two results per issue), halving the VALU cost of the GEGLU epilogue, which at K = 320 is as
+// long as the tile's MFMA work.  Same A&S 7.1.25 approximation as gelu_erf_f:
+//   Phi(x) = 0.5 + copysign(0.5 - 0.5 erfc(|x|/sqrt2), x)
+__device__ __forceinline__ f32x2_t geglu_pair(f32x2_t value, f32x2_t gate) {
+    const f32x2_t ax = {__builtin_fabsf(gate[0]), __builtin_fabsf(gate[1])};
+    const f32x2_t z = ax * 0.70710678118654752f;
+    const f32x2_t d = __builtin_elementwise_fma(z, f32x2_t{0.47047f, 0.47047f}, f32x2_t{1.0f, 1.0f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t poly = __builtin_elementwise_fma(t, f32x2_t{0.7478556f, 0.7478556f}, f32x2_t{-0.0958798f, -0.0958798f});
+    poly = __builtin_elementwise_fma(poly, t, f32x2_t{0.3480242f, 0.3480242f});
+    poly = poly * t * 0.5f;                                       // 0.5 * (a1 t + a2 t^2 + a3 t^3)
+    const f32x2_t zz = z * z * -1.4426950408889634f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+    const f32x2_t u = __builtin_elementwise_fma(poly, -e, f32x2_t{0.5f, 0.5f});      // 0.5 - 0.5 erfc(|x|/sqrt2) >= 0
+    const f32x2_t su = {__builtin_copysignf(u[0], gate[0]), __builtin_copysignf(u[1], gate[1])};
+    const f32x2_t phi = su + 0.5f;
+    return value * gate * phi;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -390,8 +390,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
 #ifdef GEGLU_NOGELU
             return u32x2{pack2bf(va[0] * vg[0], va[1] * vg[1]), pack2bf(va[2] * vg[2], va[3] * vg[3])};
 #endif
-            return u32x2{pack2bf(va[0] * gelu_erf_f(vg[0]), va[1] * gelu_erf_f(vg[1])),
-                         pack2bf(va[2] * gelu_erf_f(vg[2]), va[3] * gelu_erf_f(vg[3]))};
+            const f32x2_t lo = geglu_pair(f32x2_t{va[0], va[1]}, f32x2_t{vg[0], vg[1]});
+            const f32x2_t hi = geglu_pair(f32x2_t{va[2], va[3]}, f32x2_t{vg[2], vg[3]});
+            return u32x2{pack2bf(lo[0], lo[1]), pack2bf(hi[0], hi[1])};
         };
         auto geglu_narrow = [&](int a) {
             const int n = en0 + wn * WTN + a * 16;
