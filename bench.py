@@ -157,7 +157,7 @@ def main():
     assert torch.isfinite(final).all(), "non-finite latents"
 
     res = {
-        "metric": "512x512 images/sec at 50 DDIM steps",
+        "metric": f"512x512 images/sec at {args.ddim_steps} {args.scheduler.upper()} steps",   # default: BASELINE's metric
         "value": gb * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
