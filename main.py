@@ -1,29 +1,32 @@
-"""Entry point with the reference's CLI (``main.py:10-24``): ``python main.py --config ddim_config.yaml``
-loads ``./configs/<file>``, seeds, and dispatches ``methods_registry[method](config).run_experiment()``."""
+"""The reference's command line (``main.py:10-24``): ``python main.py --config ddim_config.yaml`` reads
+``./configs/<file>``, seeds the host RNGs and runs ``methods_registry[experiment.method](config).run_experiment()``."""
 import argparse
 import random
 
 import torch
 
-import sonicdiffusionbayeslab_amd  # noqa: F401  (registers the plugins)
+import sonicdiffusionbayeslab_amd  # noqa: F401  (importing the package registers the plugins)
 from sonicdiffusionbayeslab_amd.config import load_named_config
 from sonicdiffusionbayeslab_amd.registry import methods_registry
 
 
-def setup_seed(seed):
+def setup_seed(seed: int) -> None:
     """``src/utils/model_utils.py:15-17``."""
     random.seed(seed)
     torch.random.manual_seed(seed)
 
 
-def main(config_file):
-    config = load_named_config(config_file)
-    setup_seed(config.experiment.get("seed", 29))
-    methods_registry[config.experiment.method](config).run_experiment()
+def run(config_file: str) -> None:
+    cfg = load_named_config(config_file)
+    setup_seed(cfg.experiment.get("seed", 29))
+    method_cls = methods_registry[cfg.experiment.method]
+    method_cls(cfg).run_experiment()
+
+
+main = run      # the reference's name for the same function
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser(description="Sonic Diffusion (MI355X-native hot path)")
-    parser.add_argument("--config", type=str, default="config.yaml", help="Path to the config file")
-    args = parser.parse_args()
-    main(args.config)
+    cli = argparse.ArgumentParser(description="Sonic Diffusion sampling experiments on the MI355X-native hot path")
+    cli.add_argument("--config", type=str, default="config.yaml", help="file name inside ./configs")
+    run(cli.parse_args().config)

@@ -1,9 +1,8 @@
-from .base_experiment import BaseMethod  # noqa: F401
-from .consistency_model import ConsistencyModelMethod  # noqa: F401
-from .ddim import DDIMMethod  # noqa: F401
-from .default_sd import DefaultStableDiffusion  # noqa: F401
-from .deep_cache import DeepCacheMethod  # noqa: F401
-from .dpm_solver import DPMSolverMethod  # noqa: F401
-from .interliving_exp import InterlivingSchedulerMethod  # noqa: F401
-from .skip_steps_exp import SkipStepsMethod  # noqa: F401
-from .two_schedulers import TwoSchedulerMethod  # noqa: F401
+"""Importing this package registers every method plugin (``src/experiments/__init__.py``)."""
+import importlib
+
+for _name in ("base_experiment", "ddim", "dpm_solver", "consistency_model", "deep_cache", "default_sd",
+              "two_schedulers", "interliving_exp", "skip_steps_exp"):
+    importlib.import_module(f"{__name__}.{_name}")
+
+from .base_experiment import BaseMethod  # noqa: E402,F401

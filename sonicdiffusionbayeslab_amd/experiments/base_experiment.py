@@ -66,19 +66,39 @@ class BaseMethod(ABC):
     def setup_loggers(self):
         self.logger = None
 
-    def generate(self, test_dataloader, steps: int, batch_size: int = 1, guidance_scale: float = 7.5):
-        gen_images_list, x0_preds = [], []
+    def generate(self, test_dataloader, steps=None, batch_size: int = 1, guidance_scale: float = 7.5, **call_kwargs):
+        """One pass over the prompt batches through ``self.model(...)`` (``base_experiment.py:122-163``).
+        ``steps`` becomes ``num_inference_steps``; pipelines with other step arguments (the variant
+        pipelines) receive theirs through ``call_kwargs``."""
+        if steps is not None:
+            call_kwargs["num_inference_steps"] = steps
+        limit = self.config.inference.get("batch_count", None)
+        out_type = self.config.inference.get("output_type", "latent")
+        images, x0_preds = [], []
         for idx, batch in enumerate(test_dataloader):
-            bc = self.config.inference.get("batch_count", None)
-            if bc is not None and idx >= bc:
+            if limit is not None and idx >= limit:
                 break
-            imgs, inference_time, x0_preds = self.model(
-                batch["prompt"], num_inference_steps=steps, guidance_scale=guidance_scale,
-                generator=self.generator, output_type=self.config.inference.get("output_type", "latent"))
-            imgs = imgs.images.cpu()
-            gen_images_list.extend(imgs[i] for i in range(imgs.shape[0]))
-            self.time_metric.update(inference_time, batch_size)          # configured size, as :161
-        return gen_images_list, x0_preds
+            result, seconds, x0_preds = self.model(batch["prompt"], guidance_scale=guidance_scale,
+                                                   generator=self.generator, output_type=out_type, **call_kwargs)
+            host = result.images.cpu()
+            images.extend(host[i] for i in range(host.shape[0]))
+            self.time_metric.update(seconds, batch_size)                 # configured size, as :161
+        return images, x0_preds
+
+    def sweep(self, points, call_kwargs, label, extra=None, guidance_scale: float = 7.5):
+        """The loop every method's ``run_experiment`` is: for each sweep point move the model to the device,
+        generate, move it back, report (``src/experiments/ddim.py:26-57`` and its siblings).
+        ``call_kwargs(point)`` -> keyword arguments of the pipeline call, ``label(point)`` -> run name,
+        ``extra(point)`` -> additional logged values."""
+        batch_size = self.config.inference.get("batch_size", 1)
+        self.metric_dict = defaultdict(list)
+        for point in points:
+            self.model.to(self.device)
+            images, _ = self.generate(self.test_dataset.batches(batch_size), None, batch_size,
+                                      guidance_scale=guidance_scale, **call_kwargs(point))
+            self.model.to("cpu")
+            self.validate(f"{self.config.experiment_name}, {label(point)}",
+                          additional_values=extra(point) if extra else None, n_images=len(images))
 
     def validate(self, name_images, additional_values=None, n_images=0):
         """Only the hot-path metric survives: seconds / image over the loop (``time_metric``)."""

@@ -1,6 +1,4 @@
 """``methods_registry["ddim"]`` (``src/experiments/ddim.py:11-57``): sweep over num_inference_steps."""
-from collections import defaultdict
-
 from ..registry import methods_registry
 from .base_experiment import BaseMethod
 
@@ -11,10 +9,4 @@ class DDIMMethod(BaseMethod):
         self.num_inference_steps = self.config.experiment_params.num_inference_steps
 
     def run_experiment(self):
-        batch_size = self.config.inference.get("batch_size", 1)
-        self.metric_dict = defaultdict(list)
-        for steps in self.num_inference_steps:
-            self.model.to(self.device)
-            gen_images, _ = self.generate(self.test_dataset.batches(batch_size), steps, batch_size)
-            self.model.to("cpu")
-            self.validate(f"{self.config.experiment_name}, Inference steps: {steps}", n_images=len(gen_images))
+        self.sweep(self.num_inference_steps, lambda n: {"num_inference_steps": n}, lambda n: f"Inference steps: {n}")

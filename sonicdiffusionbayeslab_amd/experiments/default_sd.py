@@ -1,7 +1,5 @@
 """``methods_registry["default"]`` (``src/experiments/default_sd.py:10-100``): the checkpoint's own
 scheduler (PNDM/PLMS, never swapped: ``:15-16``) swept over ``num_inference_steps``."""
-from collections import defaultdict
-
 from ..registry import methods_registry, schedulers_registry
 from .base_experiment import BaseMethod
 
@@ -15,10 +13,4 @@ class DefaultStableDiffusion(BaseMethod):
         self.model.scheduler = schedulers_registry["pndm_scheduler"].from_config(self.model.scheduler.config)
 
     def run_experiment(self):
-        batch_size = self.config.inference.get("batch_size", 1)
-        self.metric_dict = defaultdict(list)
-        for steps in self.num_inference_steps:
-            self.model.to(self.device)
-            gen_images, _ = self.generate(self.test_dataset.batches(batch_size), steps, batch_size)
-            self.model.to("cpu")
-            self.validate(f"{self.config.experiment_name}, Inference steps: {steps}", n_images=len(gen_images))
+        self.sweep(self.num_inference_steps, lambda n: {"num_inference_steps": n}, lambda n: f"Inference steps: {n}")

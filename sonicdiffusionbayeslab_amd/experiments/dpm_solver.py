@@ -3,8 +3,6 @@
 Appendix-B quirk #1: the reference reads ``experiment_params.algorithm_type`` and
 ``.final_sigmas_type`` which ``configs/dpm_solver_config.yaml`` does not define; the intended
 defaults (BASELINE config 3: DPM-Solver++, final sigma zero) are applied when absent."""
-from collections import defaultdict
-
 from ..registry import methods_registry
 from .base_experiment import BaseMethod
 
@@ -17,17 +15,11 @@ class DPMSolverMethod(BaseMethod):
         self.solver_order = ep.solver_order
         self.algorithm_type = ep.get("algorithm_type", "dpmsolver++")
         self.final_sigmas_type = ep.get("final_sigmas_type", "zero" if self.algorithm_type.endswith("++") else "sigma_min")
-        self.batch_size = self.config.inference.get("batch_size", 1)
 
     def setup_scheduler(self, **kwargs):
         return super().setup_scheduler(solver_order=self.solver_order, algorithm_type=self.algorithm_type,
                                        final_sigmas_type=self.final_sigmas_type)
 
     def run_experiment(self):
-        self.metric_dict = defaultdict(list)
-        for steps in self.num_inference_steps:
-            self.model.to(self.device)
-            gen_images, _ = self.generate(self.test_dataset.batches(self.batch_size), steps, self.batch_size)
-            self.model.to("cpu")
-            self.validate(f"{self.config.experiment_name}, Solver order: {self.solver_order}, Inference steps: {steps}",
-                          n_images=len(gen_images))
+        self.sweep(self.num_inference_steps, lambda n: {"num_inference_steps": n},
+                   lambda n: f"Solver order: {self.solver_order}, Inference steps: {n}")
