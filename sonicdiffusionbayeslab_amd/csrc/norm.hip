@@ -217,6 +217,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     }
 }
 
+// LayerNorm for C = 40 * LPR (320 / 640 / 1280: every SD-1.5 transformer width): LPR = 8 / 16 / 32 lanes share a
+// row, 5 chunks of 8 channels per lane, so all 64 lanes work (one wave per row leaves 24 of 64 lanes idle at
+// C = 320) and a wave covers 64 / LPR rows.  Lane j of a row group reads chunks j, j + LPR, ...: 16 * LPR contiguous
+// bytes per load instruction and row.  Two-pass statistics in registers, reductions by xor-shuffles inside the group.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_grouped_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                int rows, float eps) {
+    constexpr int C = 40 * LPR, RPW = 64 / LPR;                  // channels, rows per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    const bf16_t* xr = x + (live ? row : 0) * C;
+    float f[5][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const u32x4 v = *(const u32x4*)(xr + (sub + i * LPR) * 8);
+        f[i][0] = bflo(v[0]); f[i][1] = bfhi(v[0]); f[i][2] = bflo(v[1]); f[i][3] = bfhi(v[1]);
+        f[i][4] = bflo(v[2]); f[i][5] = bfhi(v[2]); f[i][6] = bflo(v[3]); f[i][7] = bfhi(v[3]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[i][j];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+    bf16_t* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int ch = sub + i * LPR;
+        const f32x4 g0 = *(const f32x4*)(gamma + ch * 8), g1 = *(const f32x4*)(gamma + ch * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + ch * 8), b1 = *(const f32x4*)(beta + ch * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+            o[j + 4] = (f[i][j + 4] - mean) * rstd * g1[j] + b1[j];
+        }
+        u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+        *(u32x4*)(yr + ch * 8) = ov;
+    }
+}
+
 // one wave per row; the row lives in registers (cols <= 4096)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ s, long rows, int cols, float scale) {
     const int lane = threadIdx.x & 63;
@@ -307,7 +360,16 @@ int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, 
     SD_REQUIRE(x && y && gamma && beta, "layernorm: null operand");
     SD_REQUIRE(C % 8 == 0 && C > 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
     SD_REQUIRE(rows > 0, "layernorm: no rows");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
+    auto grouped = [&](auto kern, int lpr) {
+        const int rows_per_block = 4 * (64 / lpr);
+        hipLaunchKernelGGL(kern, dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), 0, stream, x, gamma, beta, y,
+                           rows, eps);
+    };
+    if (C == 320) grouped(layernorm_grouped_kernel<8>, 8);
+    else if (C == 640) grouped(layernorm_grouped_kernel<16>, 16);
+    else if (C == 1280) grouped(layernorm_grouped_kernel<32>, 32);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }
