@@ -7,6 +7,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct GnGeom {
@@ -163,6 +165,53 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
         apply(v0, base + p); apply(v1, base + p + rp); apply(v2, base + p + 2 * rp); apply(v3, base + p + 3 * rp);
     }
     for (; p < pend; p += rp) apply(*(const u32x4*)gn_src(a, base + p, c0), base + p);
+}
+
+// Single-launch GroupNorm(+SiLU) for the smallest images (HW <= 64: the 8x8 level), one workgroup per
+// (batch item, group).  The three-launch path above costs ~3 x 5 us of launch floor there for a few hundred KB of
+// data; here the group's HW x cpg values (<= 10 KB) are read twice by the same workgroup (the second time from
+// L1/L2), with a block reduction in between (measured 18 -> 9 us at 8x8; at 16x16 it loses to the split path).  Accesses are 8 bytes (4 channels): cpg is a multiple of 4 at these
+// levels (20 / 40 / 60 / 80) but not of 8.
+__global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
+    __shared__ float2 red[4];
+    const int C = a.C1 + a.C2, cpg = C / a.groups, upp = cpg >> 2;      // 4-channel units per pixel
+    const int grp = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = a.HW * upp;
+    const long base = (long)b * a.HW;
+    auto src = [&](int p, int c) -> const bf16_t* {
+        return c < a.C1 ? a.x1 + (base + p) * a.C1 + c : a.x2 + (base + p) * a.C2 + (c - a.C1);
+    };
+    float s = 0.f, q = 0.f;
+    for (int i = tid; i < total; i += 256) {
+        const int p = i / upp, c = grp * cpg + (i - p * upp) * 4;
+        const u32x2 v = *(const u32x2*)src(p, c);
+        const float f0 = bflo(v[0]), f1 = bfhi(v[0]), f2 = bflo(v[1]), f3 = bfhi(v[1]);
+        s += (f0 + f1) + (f2 + f3);
+        q += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = make_float2(s, q);
+    __syncthreads();
+    const float ts = (red[0].x + red[1].x) + (red[2].x + red[3].x);
+    const float tq = (red[0].y + red[1].y) + (red[2].y + red[3].y);
+    const float cnt = (float)a.HW * (float)cpg;
+    const float mean = ts / cnt;
+    const float rstd = rsqrtf(fmaxf(tq / cnt - mean * mean, 0.f) + a.eps);
+    for (int i = tid; i < total; i += 256) {
+        const int p = i / upp, c = grp * cpg + (i - p * upp) * 4;
+        const u32x2 v = *(const u32x2*)src(p, c);
+        const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+        float f[4] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[j] = (f[j] - mean) * rstd * gm[j] + bt[j];
+            if (a.silu) f[j] = silu_f(f[j]);
+        }
+        u32x2 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
+        *(u32x2*)(a.y + (base + p) * C + c) = o;
+    }
 }
 
 // one wave per token row; up to 3 chunks of 8 channels per lane (C <= 1536)
@@ -347,6 +396,12 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     SD_REQUIRE(a.nsplit >= 1 && a.nsplit <= a.HW && a.B > 0 && a.HW > 0, "groupnorm: bad split %d for HW=%d", a.nsplit, a.HW);
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
+    static const bool no_small = getenv("SD_GN_NO_SMALL") != nullptr;
+    if (!no_small && a.HW <= 64 && (C / a.groups) % 4 == 0 && a.C1 % 4 == 0 && a.B <= 65535) {
+        hipLaunchKernelGGL(gn_small_kernel, dim3(a.groups, a.B), dim3(256), 0, stream, a);
+        SD_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     dim3 grid(a.nsplit, a.B);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), (g.threads + g.nchunks) * sizeof(float4), stream, a);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);

@@ -150,7 +150,9 @@ def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
     (2, 256, 320, 0, 1, 1e-5),
     (2, 64, 640, 320, 1, 1e-5),     # concat 960: groups of 30 straddle the tensor boundary
     (1, 1024, 1280, 1280, 0, 1e-6),
-    (3, 16, 1280, 640, 1, 1e-5),
+    (3, 16, 1280, 640, 1, 1e-5),    # single-launch small-image kernel, a group straddles the concat boundary
+    (2, 64, 1280, 1280, 1, 1e-5),   # small-image kernel at the 8x8 level (80 channels per group)
+    (5, 64, 1280, 0, 0, 1e-6),      # ... 40 channels per group, no SiLU
 ])
 def test_groupnorm(sdlib, B, HW, C1, C2, silu, eps):
     g = torch.Generator().manual_seed(HW + C1)
