@@ -167,10 +167,11 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
     for (; p < pend; p += rp) apply(*(const u32x4*)gn_src(a, base + p, c0), base + p);
 }
 
-// Single-launch GroupNorm(+SiLU) for the smallest images (HW <= 64: the 8x8 level), one workgroup per
+// Single-launch GroupNorm(+SiLU) for small images (a group of <= 10240 values: the 8x8 level, and the 16x16
+// level up to 1280 channels), one workgroup per
 // (batch item, group).  The three-launch path above costs ~3 x 5 us of launch floor there for a few hundred KB of
 // data; here the group's HW x cpg values (<= 10 KB) are read twice by the same workgroup (the second time from
-// L1/L2), with a block reduction in between (measured 18 -> 9 us at 8x8; at 16x16 it loses to the split path).  Accesses are 8 bytes (4 channels): cpg is a multiple of 4 at these
+// L1/L2), with a block reduction in between (measured 18 -> 8 us at 8x8, 20 -> 16 us at 16x16 x 1280; wider 16x16 tensors stay on the split path).  Accesses are 8 bytes (4 channels): cpg is a multiple of 4 at these
 // levels (20 / 40 / 60 / 80) but not of 8.
 __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     __shared__ float2 red[4];
@@ -182,10 +183,14 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     auto src = [&](int p, int c) -> const bf16_t* {
         return c < a.C1 ? a.x1 + (base + p) * a.C1 + c : a.x2 + (base + p) * a.C2 + (c - a.C1);
     };
+    // unit i = tid + 256 j  <->  (pixel p, unit k): stepped incrementally, no division in the loops
+    const int p0 = tid / upp, k0 = tid - p0 * upp, dp = 256 / upp, dk = 256 - dp * upp;
     float s = 0.f, q = 0.f;
-    for (int i = tid; i < total; i += 256) {
-        const int p = i / upp, c = grp * cpg + (i - p * upp) * 4;
+    for (int i = tid, p = p0, k = k0; i < total; i += 256) {
+        const int c = grp * cpg + k * 4;
         const u32x2 v = *(const u32x2*)src(p, c);
+        p += dp; k += dk;
+        if (k >= upp) { k -= upp; ++p; }
         const float f0 = bflo(v[0]), f1 = bfhi(v[0]), f2 = bflo(v[1]), f3 = bfhi(v[1]);
         s += (f0 + f1) + (f2 + f3);
         q += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
@@ -199,9 +204,11 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     const float cnt = (float)a.HW * (float)cpg;
     const float mean = ts / cnt;
     const float rstd = rsqrtf(fmaxf(tq / cnt - mean * mean, 0.f) + a.eps);
-    for (int i = tid; i < total; i += 256) {
-        const int p = i / upp, c = grp * cpg + (i - p * upp) * 4;
+    for (int i = tid, pp = p0, k = k0; i < total; i += 256) {
+        const int p = pp, c = grp * cpg + k * 4;
         const u32x2 v = *(const u32x2*)src(p, c);
+        pp += dp; k += dk;
+        if (k >= upp) { k -= upp; ++pp; }
         const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
         float f[4] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
 #pragma unroll
@@ -397,7 +404,7 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
     static const bool no_small = getenv("SD_GN_NO_SMALL") != nullptr;
-    if (!no_small && a.HW <= 64 && (C / a.groups) % 4 == 0 && a.C1 % 4 == 0 && a.B <= 65535) {
+    if (!no_small && a.HW <= 256 && (long)a.HW * (C / a.groups) <= 10240 && (C / a.groups) % 4 == 0 && a.C1 % 4 == 0 && a.B <= 65535) {
         hipLaunchKernelGGL(gn_small_kernel, dim3(a.groups, a.B), dim3(256), 0, stream, a);
         SD_CHECK_HIP(hipGetLastError());
         return 0;
