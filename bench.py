@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--sample-size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (text encode + loop + VAE decode) report")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -73,6 +74,42 @@ def cpu_baseline(cfg, sd, args):
             "kind": "port",
             "sample": f"{n_done} of {args.ddim_steps} DDIM steps (CFG pair UNet forward + step, batch 1, fp32 "
                       f"PyTorch-CPU oracle) in {dt:.1f}s, extrapolated to {args.ddim_steps} steps"}
+
+
+def end_to_end(model, args, dev):
+    """next to the loop-only number, the time of one whole call from prompt STRINGS to decoded
+    512x512 images -- CLIP text encoding (libsdhip text tower, seeded synthetic ViT-L/14-shaped weights, merge-free
+    byte-level tokenizer: no CLIP checkpoint exists offline), the sampling loop, and the VAE decode (libsdhip
+    AutoencoderKL decoder, synthetic weights).  Not part of `value`; the reference's timer covers the loop only."""
+    import json as _json
+    from sonicdiffusionbayeslab_amd.clip import (ClipBpeTokenizer, ClipPromptEncoder, ClipTextConfig, HipClipTextModel,
+                                                 make_synthetic_clip_state_dict)
+    tok = ClipBpeTokenizer.byte_level()
+    ccfg = ClipTextConfig(vocab_size=len(tok.encoder), bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id,
+                          pad_token_id=tok.pad_token_id)
+    enc = ClipPromptEncoder(tok, HipClipTextModel(ccfg, make_synthetic_clip_state_dict(ccfg, seed=777), device=str(dev)))
+    model.text_encoder = enc
+    root = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(root, "data", "dataset", "img2annotations_test.json")) as f:
+        prompts = list(_json.load(f).values())[: args.batch]
+    guidance = 0.0 if args.scheduler == "lcm" else 7.5
+    g = torch.Generator().manual_seed(29)
+    best = None
+    for _ in range(2):                                   # first pass builds the VAE / warms up
+        torch.cuda.synchronize()
+        t0 = time.time()
+        pe = enc(prompts)
+        ne = enc([""] * len(prompts)) if guidance > 1 else None
+        torch.cuda.synchronize()
+        t1 = time.time()
+        out, loop_s, _ = model(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=args.ddim_steps,
+                               guidance_scale=guidance, generator=g, output_type="pt", collect_x0=False)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        best = {"s_per_image": (t2 - t0) / len(prompts), "text_encode_ms": 1e3 * (t1 - t0), "loop_s": loop_s,
+                "vae_decode_and_postprocess_ms": 1e3 * (t2 - t1 - loop_s), "images": list(out.images.shape),
+                "note": "prompt strings -> [B,3,512,512]; synthetic CLIP / VAE weights, byte-level tokenizer"}
+    return best
 
 
 def conv_traffic_bytes():
@@ -187,6 +224,8 @@ def main():
                 "tflops": (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] and v["ms"] else None),
                 "alg_GBs": (round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None)}
             for k, v in prof.items()}
+    if rank == 0 and world == 1 and not args.no_e2e and args.sample_size == 64:
+        res["config"]["end_to_end"] = end_to_end(model, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, sd, args)
     if rank == 0:

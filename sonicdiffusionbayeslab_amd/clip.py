@@ -225,6 +225,17 @@ class ClipBpeTokenizer:
         merges = [tuple(l.split()) for l in lines if l and len(l.split()) == 2]
         return cls(vocab, merges, **kw)
 
+    @classmethod
+    def byte_level(cls, **kw) -> "ClipBpeTokenizer":
+        """A merge-free byte-level vocabulary (every byte symbol, its ``</w>`` form, the two special tokens:
+        514 ids) -- what the benchmarks tokenize with when no checkpoint vocabulary exists offline."""
+        syms = list(bytes_to_unicode().values())
+        vocab = {s: i for i, s in enumerate(syms)}
+        vocab.update({s + "</w>": len(syms) + i for i, s in enumerate(syms)})
+        vocab["<|startoftext|>"] = len(vocab)
+        vocab["<|endoftext|>"] = len(vocab)
+        return cls(vocab, [], **kw)
+
     def bpe(self, token: str) -> str:
         if token in self.cache:
             return self.cache[token]

@@ -87,3 +87,12 @@ def test_library_enumerates_clip_parameters():
     lib.sd_unet_destroy(h)
     bad = _lib.SdClipConfig(100, 96, 1, 4, 128, 16, 1e-5)      # hidden not a multiple of 64
     assert lib.sd_clip_create(C.byref(bad), C.byref(h)) != 0 and b"multiples of 64" in lib.sd_last_error()
+
+
+def test_byte_level_tokenizer():
+    tk = ClipBpeTokenizer.byte_level()
+    assert len(tk.encoder) == 514 and tk.bos_token_id == 512 and tk.eos_token_id == 513
+    ids = tk.encode("A cat")
+    assert len(ids) == 77 and ids[0] == 512 and ids[5] == 513 and ids[-1] == 513
+    sym = {v: k for k, v in tk.encoder.items()}
+    assert [sym[i] for i in ids[1:5]] == ["a</w>", "c", "a", "t</w>"]
