@@ -857,7 +857,12 @@ int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
             if (dma && !no_pipe && a.Nk % 64 == 0 && a.Nk >= 256) return launch_attn_pipe40(a, stream);
             return dma ? launch_attn_dma<40>(a, stream) : launch_attn<40>(a, stream);
         }
-        case 80: return dma ? launch_attn_dma<80>(a, stream) : launch_attn<80>(a, stream);
+        case 80: {
+            // measured at the 32x32 level (UNet batch 16): register-staged 79 us vs LDS-DMA 87 us self, 21.5 vs 23.6 us
+            // cross -- the 8-wave DMA workgroups only pay off at d = 40; SD_ATTN_DMA80 re-selects the DMA kernel
+            static const bool dma80 = getenv("SD_ATTN_DMA80") != nullptr;
+            return (dma && dma80) ? launch_attn_dma<80>(a, stream) : launch_attn<80>(a, stream);
+        }
         case 160: return launch_attn<160>(a, stream);
         default: sd_set_error("attention: head dim %d not supported (40, 80, 160)", a.D); return -1;
     }
