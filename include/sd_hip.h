@@ -143,6 +143,13 @@ int sd_sched_step(void* stream, const float* eps, int cfg, float guidance, const
 int sd_op_gemm(void* stream, const void* X, long long ldx, const void* X2, long long ldx2, int K1, const void* W,
                const float* bias, const float* bias2, const void* R, long long ldr, void* C, long long ldc, int M,
                int N, int K, int epi);
+/* Same GEMM with a PER-SAMPLE weight matrix: rows [b*rows_per_batch, (b+1)*rows_per_batch) use W + b*w_batch_stride
+ * (elements; rows_per_batch a multiple of 128).  epi=2: row softmax over the first sm_valid of every 80 output
+ * columns, the rest written as 0.  The two halves of the folded prompt cross-attention
+ * (Y = R + sum_h softmax_77(X A_h) B_h, src/models.py:227 -> diffusers Attention with 77 keys) are these two calls. */
+int sd_op_gemm_batched(void* stream, const void* X, long long ldx, const void* W, long long w_batch_stride,
+                       int rows_per_batch, const float* bias, const void* R, long long ldr, void* C, long long ldc,
+                       int M, int N, int K, int epi, int sm_valid);
 /* NHWC 3x3 conv, pad 1, stride 1|2, optional fused nearest-2x upsample; W is bf16
  * [Cout][Cin/64][3*3][64] (K runs over 64-channel slice, tap, channel) */
 int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2, const void* R,

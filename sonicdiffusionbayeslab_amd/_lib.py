@@ -66,6 +66,7 @@ _SIGS = {
     "sd_unet_debug_tensor": (_i, [_vp, _vp, C.c_char_p, _vp, _ll, _vp, _i, _i]),
     "sd_sched_step": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _ll]),
     "sd_op_gemm": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i]),
+    "sd_op_gemm_batched": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i]),
     "sd_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "sd_op_groupnorm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "sd_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),

@@ -24,6 +24,7 @@ constexpr int AMODE_GEMM = 0;
 constexpr int AMODE_CONV = 1;
 constexpr int EPI_STD = 0;
 constexpr int EPI_GEGLU = 1;
+constexpr int EPI_SOFTMAX = 2;   // row softmax over every 80-column group (one group per N-wave), std stores
 
 constexpr int kPersistentGrid = 512;   // 2 workgroups per CU x 256 CUs
 
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     for (int i = 0; i < WPW; ++i) {
         const int inst = wave + i * NW;
         const int n = n0 + inst * 8 + lrow8;
-        wsrc[i] = (inst < WI && n < p.N) ? p.W + (long)n * p.ldw + gch * 8 : nullptr;
+        const long wb = p.rows_per_batch > 0 ? (long)(m0 / p.rows_per_batch) * p.w_batch_stride : 0;
+        wsrc[i] = (inst < WI && n < p.N) ? p.W + wb + (long)n * p.ldw + gch * 8 : nullptr;
     }
     };
 
@@ -315,6 +317,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         }
     }
 
+    if (EPI == EPI_SOFTMAX) {
+        // Each N-wave owns one 80-column group (WTN = 80): softmax over its first sm_valid columns, the rest -> 0.
+        // A lane holds 4 consecutive columns per 16-column tile; the 4 lane groups lq of a row sit 16 lanes apart.
+        static_assert(EPI != EPI_SOFTMAX || WTN == 80, "softmax epilogue: one 80-column group per N-wave");
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (a * 16 + lq * 4 + j < p.sm_valid) mx = fmaxf(mx, acc[a][b][j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = a * 16 + lq * 4 + j < p.sm_valid
+                                        ? __builtin_amdgcn_exp2f((acc[a][b][j] - mx) * 1.4426950408889634f) : 0.f;
+                    acc[a][b][j] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) acc[a][b] *= inv;
+        }
+    }
+
     // ---- next work item: descriptors + first K tile in flight before the stores of this one -------
     work += gridDim.x;
     const bool more_work = work < nwork;
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 *(f32x4*)(slab + (long)m * p.N + n) = acc[a][b];
             }
         }
-    } else if (EPI == EPI_STD) {
+    } else if (EPI == EPI_STD || EPI == EPI_SOFTMAX) {
         // Stores are issue-bound (one 8-B store per lane per 16x16 tile): v_permlane16_swap pairs two
         // adjacent tiles so that every lane owns 16 contiguous bytes -> half the store instructions,
         // 64 contiguous bytes per row per instruction.  After the swap lane group lq holds
@@ -524,6 +558,14 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
         if (big_tile_mode() != 3 && a.N % 256 == 0) return launch<256, 256, 4, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
         return launch<128, 128, 2, 2, 2, AMODE_GEMM, EPI_GEGLU>(a, stream);
     }
+    SD_REQUIRE(a.rows_per_batch == 0 || a.rows_per_batch % 128 == 0,
+               "gemm: rows_per_batch=%d must be a multiple of the 128-row tile", a.rows_per_batch);
+    if (epi == EPI_SOFTMAX) {
+        SD_REQUIRE(a.N % 80 == 0 && a.sm_valid > 0 && a.sm_valid <= 80 && a.R == nullptr && a.bias == nullptr,
+                   "softmax gemm: N=%d must be a multiple of 80, 0 < sm_valid=%d <= 80, no bias/residual", a.N, a.sm_valid);
+        return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_SOFTMAX>(a, stream);
+    }
+    if (a.rows_per_batch) return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);   // tiles must not straddle samples
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
     if (big_tile_mode() == 2) return launch<256, 160, 4, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
     return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);

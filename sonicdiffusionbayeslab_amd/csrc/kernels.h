@@ -25,12 +25,17 @@ struct GemmArgs {
     int splitk = 1;                   // > 1: K is split over blocks, fp32 partials go through `slab`
     float* slab = nullptr;            // [splitk, M, N] fp32 scratch (required when splitk > 1)
     const void* zero_page = nullptr;  // >= 16 zero bytes in device memory
+    // per-sample W (cross-attention folded into two GEMMs): rows [b*rows_per_batch, (b+1)*rows_per_batch) of X use
+    // W + b * w_batch_stride; rows_per_batch must be a multiple of the 128-row tile (0 = one W for all rows)
+    long w_batch_stride = 0;
+    int rows_per_batch = 0;
+    int sm_valid = 0;                 // EPI 2: softmax over the first sm_valid of every 80 output columns
     int tiles_m = 0, tiles_n = 0;     // filled by the launcher
     int tune = 0;                     // experiment knobs, filled by the launcher from SD_GEMM_TUNE
 };
 
 int sd_gemm_splitk(int M, int N, int K);   // heuristic split factor (1 = none) for the std epilogue
-int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu*/, hipStream_t stream);
+int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu, 2 softmax over 80-column groups*/, hipStream_t stream);
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
 void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // slab -> C (+bias +bias2 +R)
 // conv_halo.hip: LDS-resident-halo kernel for stride-1 convs on whole-row tiles

@@ -1350,6 +1350,18 @@ extern "C" int sd_op_gemm(void* stream, const void* X, long long ldx, const void
     return sd_launch_gemm(a, epi, (hipStream_t)stream);
 }
 
+extern "C" int sd_op_gemm_batched(void* stream, const void* X, long long ldx, const void* W, long long w_batch_stride,
+                                  int rows_per_batch, const float* bias, const void* R, long long ldr, void* C,
+                                  long long ldc, int M, int N, int K, int epi, int sm_valid) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(epi == 0 || epi == 2, "sd_op_gemm_batched: epi %d (0 = std, 2 = softmax over 80-column groups)", epi);
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.ldr = ldr;
+    a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
+    a.w_batch_stride = w_batch_stride; a.rows_per_batch = rows_per_batch; a.sm_valid = sm_valid; a.splitk = 1;
+    return sd_launch_gemm(a, epi, (hipStream_t)stream);
+}
+
 extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2,
                              const void* R, void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample) {
     if (ensure_zero_page()) return -2;

@@ -281,3 +281,34 @@ def test_sched_step_kernel(sdlib):
     torch.cuda.synchronize()
     for got, ref in zip(o, (prev, y2, mo)):
         assert torch.allclose(got.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,rows,N,K,epi", [(3, 256, 640, 320, 2), (2, 128, 320, 640, 0), (4, 1024, 640, 640, 2)])
+def test_gemm_batched_weights_and_grouped_softmax(sdlib, B, rows, N, K, epi):
+    """Per-sample W (+ residual / bias) and the softmax-over-77-of-80 epilogue: the two GEMMs of the folded
+    prompt cross-attention."""
+    g = torch.Generator().manual_seed(rows + N)
+    x = r16(torch.randn(B * rows, K, generator=g))
+    w = r16(torch.randn(B, N, K, generator=g) / math.sqrt(K) * (4.0 if epi else 1.0))
+    xb = x.view(B, rows, K)
+    ref = torch.einsum("brk,bnk->brn", xb, w)
+    if epi == 2:
+        s = ref.view(B, rows, N // 80, 80)
+        p = torch.zeros_like(s)
+        p[..., :77] = torch.softmax(s[..., :77], dim=-1)
+        ref = p.view(B * rows, N)
+        bias = res = None
+    else:
+        bias = torch.randn(N, generator=g)
+        res = r16(torch.randn(B * rows, N, generator=g))
+        ref = ref.reshape(B * rows, N) + bias + res
+    out = torch.full((B * rows, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_gemm_batched(stream(), P(x, torch.bfloat16), K, P(w, torch.bfloat16), N * K, rows,
+                                        P(bias) if bias is not None else None,
+                                        P(res, torch.bfloat16) if res is not None else None, N, P(out), N,
+                                        B * rows, N, K, epi, 77 if epi else 0))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL
+    if epi == 2:
+        o = out.float().view(B * rows, N // 80, 80)
+        assert (o[..., 77:] == 0).all() and (o.sum(-1) - 1).abs().max() < 2e-2
