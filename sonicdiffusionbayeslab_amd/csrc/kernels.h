@@ -83,6 +83,9 @@ int sd_launch_gemv(const float* x, const bf16_t* W, const float* b, float* y, in
                    hipStream_t stream);
 int sd_launch_timestep_sinusoid(float t, float* out, int dim, hipStream_t stream);
 int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
+int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream);
+int sd_launch_xattn_expand(const bf16_t* kv, bf16_t* out, int B, int L, int C, int NH, int col_off, float scale,
+                           hipStream_t stream);
 // clip.hip: CLIP text encoder pieces
 int sd_launch_clip_embed(const int* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* out, int rows, int L, int H,
                          int vocab, hipStream_t stream);

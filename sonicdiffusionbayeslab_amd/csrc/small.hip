@@ -203,6 +203,54 @@ int sd_launch_gemv(const float* x, const bf16_t* W, const float* b, float* y, in
     return 0;
 }
 
+// out[b][h*80 + j][c] = (j < L and c in head h) ? scale * kv[b*L + j][col_off + c] : 0   (kv rows are [K | V], 2C wide)
+__global__ void xattn_expand_kernel(const bf16_t* __restrict__ kv, bf16_t* __restrict__ out, int L, int C, int NH,
+                                    int col_off, float scale) {
+    const int row = blockIdx.x;                       // b * NH * 80 + h * 80 + j
+    const int j = row % 80, h = (row / 80) % NH, b = row / (80 * NH);
+    const int d = C / NH;
+    const bf16_t* src = kv + ((long)b * L + (j < L ? j : 0)) * 2 * C + col_off;
+    bf16_t* dst = out + (long)row * C;
+    for (int c = threadIdx.x * 2; c < C; c += blockDim.x * 2) {
+        unsigned v = 0;
+        if (j < L && c / d == h) {                    // d is even: a channel pair never straddles heads
+            const unsigned u = *(const unsigned*)(src + c);
+            v = pack2bf(bflo(u) * scale, bfhi(u) * scale);
+        }
+        *(unsigned*)(dst + c) = v;
+    }
+}
+
+// dst[b][c][r] = src[b][r][c]  (bf16, 32x32 tiles through LDS)
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc) {
+    __shared__ bf16_t tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    const bf16_t* s = src + (long)b * R * Cc;
+    bf16_t* d = dst + (long)b * R * Cc;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < Cc) tile[i][tx] = s[(long)(r0 + i) * Cc + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < Cc && r0 + tx < R) d[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream) {
+    SD_REQUIRE(src && dst && B > 0 && B <= 65535 && R > 0 && Cc > 0, "transpose: B=%d R=%d C=%d", B, R, Cc);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, B), dim3(256), 0, stream, src, dst, R, Cc);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_xattn_expand(const bf16_t* kv, bf16_t* out, int B, int L, int C, int NH, int col_off, float scale,
+                           hipStream_t stream) {
+    SD_REQUIRE(kv && out && B > 0 && L > 0 && L <= 80 && NH > 0 && C % NH == 0 && (C / NH) % 2 == 0,
+               "xattn_expand: B=%d L=%d C=%d heads=%d", B, L, C, NH);
+    hipLaunchKernelGGL(xattn_expand_kernel, dim3(B * NH * 80), dim3(128), 0, stream, kv, out, L, C, NH, col_off, scale);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int sd_launch_conv_in(const float* x, int Bsrc, const float* Wt, const float* bias, bf16_t* y, int B, int H, int W,
                       int Cin, int Cout, hipStream_t stream) {
     SD_REQUIRE(x && Wt && bias && y, "conv_in: null operand");

@@ -103,6 +103,8 @@ struct Op {
     size_t wx = NOFF;
     long xoff = 0, woff_el = 0, coff = 0, ldx_o = 0, ldw_o = 0, ldc_o = 0;
     float scale = 0.f;
+    long wbs = 0;                 // per-sample W: batch stride (elements), rows per sample, softmax width
+    int rpb = 0, sm_valid = 0;
     int nwrap = 0;
     Wrap wraps[3];
 };
@@ -123,6 +125,10 @@ struct Plan {
     std::vector<size_t> ctx_w;            // packed [2C, 768] weight offset per layer
     std::vector<int> ctx_c;               // C per layer
     int ctx_bf16 = -1;                    // bf16 copy of encoder_hidden_states
+    // folded prompt cross-attention (per layer): A^T [UB][heads*80][C] and B [UB][C][heads*80], see transformer()
+    struct Fold { int kv, at, bw, C; size_t wqT, wo; };
+    std::vector<Fold> ctx_fold;
+    int ctx_fold_scratch = -1;            // masked K / V expansions [2][UB][heads*80][Cmax]
     std::map<std::string, int> taps;
     size_t total_bytes = 0;
 };
@@ -409,6 +415,13 @@ struct Packer {
         concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"});
         bf16_same(t + "attn1.to_out.0.weight"); f32(t + "attn1.to_out.0.bias");
         bf16_same(t + "attn2.to_q.weight");
+        {   // to_q transposed ([in][out]): the W operand of A^T = (scale K_h) . W_q,h of the folded cross-attention
+            const auto& d = P(t + "attn2.to_q.weight");
+            size_t off = alloc(t + "attn2.to_q.weight.T", d.size() * 2);
+            unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+            for (int r = 0; r < c; ++r)
+                for (int k = 0; k < c; ++k) o[(size_t)r * c + k] = f32_to_bf16_host(d[(size_t)k * c + r]);
+        }
         concat_rows(t + "attn2.kv.weight", {t + "attn2.to_k.weight", t + "attn2.to_v.weight"});
         bf16_same(t + "attn2.to_out.0.weight"); f32(t + "attn2.to_out.0.bias");
         geglu(t, c);
@@ -660,14 +673,35 @@ struct Builder {
         int a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
         int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
-        int q2 = gemm(n2, C, -1, 0, M, C, t + "attn2.to_q.weight", "", -1, 0);
         // K|V of the prompt: projected once per sampling run by sd_unet_set_context
         int kv = tensor((size_t)UB * L * 2 * C * 2, /*persistent=*/true);
         pl.ctx_kv.push_back(kv);
         pl.ctx_w.push_back(W(t + "attn2.kv.weight"));
         pl.ctx_c.push_back(C);
-        int a2 = attn(q2, 0, C, kv, 0, C, 2 * C, hw, L, C);
-        int h2 = gemm(a2, C, -1, 0, M, C, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", h1, 0);
+        int h2;
+        // SD_XATTN_FOLD: 0 = never, n > 0 = levels with at most n tokens.  Default 1024 (the 32x32 and 16x16 levels):
+        // measured +0.6 % images/s; at 64x64 the P tensor (M x 640) costs as much HBM traffic as Q and O did.
+        static const int fold_max_hw = getenv("SD_XATTN_FOLD") ? atoi(getenv("SD_XATTN_FOLD")) : 1024;
+        if (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) {
+            // Folded prompt cross-attention.  The prompt is step-invariant, so per sample and head
+            //   A_h = scale * W_q,h^T K_h^T  [C x 77]   and   B_h = V_h W_o,h^T  [77 x C]
+            // are computed once per sampling run (sd_unet_set_context) and every step is two GEMMs with per-sample
+            // weights,  P = softmax_77(X A)  (80 columns per head, 3 of them padding)  and  h2 = h1 + P B + b_o:
+            // to_q, the 77-key attention kernel and to_out, with their Q / O round trips through HBM, are gone.
+            const int NH = u->cfg.num_heads, NP = NH * 80;
+            int at = tensor((size_t)UB * NP * C * 2, true), bw = tensor((size_t)UB * C * NP * 2, true);
+            pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight")});
+            int pr;
+            { Op o; o.kind = OP_GEMM; o.x1 = n2; o.K1 = C; o.K = C; o.M = M; o.N = NP; o.epi = 2; o.sm_valid = L;
+              o.wt = at; o.wbs = (long)NP * C; o.rpb = hw; o.out = tensor((size_t)M * NP * 2); push(o); pr = o.out; }
+            { Op o; o.kind = OP_GEMM; o.x1 = pr; o.K1 = NP; o.K = NP; o.M = M; o.N = C; o.epi = 0;
+              o.wt = bw; o.wbs = (long)C * NP; o.rpb = hw; o.b = W(t + "attn2.to_out.0.bias"); o.r = h1;
+              o.out = tensor((size_t)M * C * 2); push(o); h2 = o.out; }
+        } else {
+            int q2 = gemm(n2, C, -1, 0, M, C, t + "attn2.to_q.weight", "", -1, 0);
+            int a2 = attn(q2, 0, C, kv, 0, C, 2 * C, hw, L, C);
+            h2 = gemm(a2, C, -1, 0, M, C, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", h1, 0);
+        }
         int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias");
         int ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1);
         int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0);
@@ -783,6 +817,8 @@ struct Builder {
         const int nl = c.num_levels, c0 = c.block_out_channels[0], temb = 4 * c0;
         const int L = c.context_len;
         pl.ctx_bf16 = tensor((size_t)UB * L * c.cross_attention_dim * 2, true);
+        // masked K / V expansions used by sd_unet_set_context for the folded cross-attention (sized for the widest level)
+        pl.ctx_fold_scratch = tensor((size_t)2 * UB * c.num_heads * 80 * c.block_out_channels[nl - 1] * 2, true);
         // ---- time embedding (M = 1: the reference passes one scalar t per call) ----
         int t_sin = tensor((size_t)c0 * 4), t_h1 = tensor((size_t)temb * 4), t_emb = tensor((size_t)temb * 4);
         int t_proj = tensor((size_t)u->tproj_total * 4);
@@ -1003,8 +1039,9 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.W = o.wt >= 0 ? (const bf16_t*)T(o.wt) + o.woff_el : (const bf16_t*)(wb + o.w); a.ldw = o.ldw_o;
             a.bias = o.b != NOFF ? (const float*)(wb + o.b) : nullptr;
             a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out) + o.coff;
-            a.ldc = o.ldc_o ? o.ldc_o : (o.epi ? o.N / 2 : o.N);
+            a.ldc = o.ldc_o ? o.ldc_o : (o.epi == 1 ? o.N / 2 : o.N);
             a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
+            a.w_batch_stride = o.wbs; a.rows_per_batch = o.rpb; a.sm_valid = o.sm_valid;
             return sd_launch_gemm(a, o.epi, stream);
         }
         case OP_LN:
@@ -1216,6 +1253,35 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
         a.zero_page = g_zero_page;
         if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
     }
+    // folded prompt cross-attention: A^T = (scale K)_masked . W_q  and  B = W_o . V_masked^T per sample and layer
+    const int NH = u->cfg.num_heads, NP = NH * 80;
+    for (const Plan::Fold& f : pl.ctx_fold) {
+        const int C = f.C, d = C / NH;
+        const bf16_t* kvp = (const bf16_t*)(ws + pl.tensors[f.kv].off);
+        bf16_t* kexp = (bf16_t*)(ws + pl.tensors[pl.ctx_fold_scratch].off);
+        bf16_t* vexp = kexp + (size_t)unet_batch * NP * C;
+        if ((rc = sd_launch_xattn_expand(kvp, kexp, unet_batch, L, C, NH, 0, 1.0f / sqrtf((float)d), (hipStream_t)stream))) return rc;
+        if ((rc = sd_launch_xattn_expand(kvp, vexp, unet_batch, L, C, NH, C, 1.0f, (hipStream_t)stream))) return rc;
+        {   // A^T [UB*NP, C]: rows (sample, head, key), K-contiguous over the UNet channel -> W operand of GEMM 1
+            GemmArgs a;
+            a.X = kexp; a.ldx = C; a.K1 = C; a.K = C; a.M = unet_batch * NP; a.N = C;
+            a.W = (const bf16_t*)(u->dweights + f.wqT);
+            a.C = (bf16_t*)(ws + pl.tensors[f.at].off); a.ldc = C;
+            a.zero_page = g_zero_page;
+            if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
+        }
+        {   // B^T [UB*NP, C] = V_masked . W_o^T (one GEMM, into the K expansion's scratch), then transposed per sample
+            // to [C, NP]: K-contiguous over (head, key) -> W operand of GEMM 2
+            GemmArgs a;
+            a.X = vexp; a.ldx = C; a.K1 = C; a.K = C; a.M = unet_batch * NP; a.N = C;
+            a.W = (const bf16_t*)(u->dweights + f.wo);
+            a.C = kexp; a.ldc = C;
+            a.zero_page = g_zero_page;
+            if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
+            if ((rc = sd_launch_transpose_bf16(kexp, (bf16_t*)(ws + pl.tensors[f.bw].off), unet_batch, NP, C, (hipStream_t)stream)))
+                return rc;
+        }
+    }
     return 0;
 }
 
@@ -1249,7 +1315,7 @@ static void op_work(const Op& o, double* flops, double* bytes) {
         case OP_CONV3:
         case OP_GEMM:
             *flops = 2.0 * o.M * o.N * o.K;
-            *bytes = 2.0 * ((double)o.M * o.K + (double)o.N * o.K + (double)o.M * (o.epi ? o.N / 2 : o.N));
+            *bytes = 2.0 * ((double)o.M * o.K + (double)o.N * o.K + (double)o.M * (o.epi == 1 ? o.N / 2 : o.N));
             break;
         case OP_ATTN:
             *flops = 4.0 * o.B * o.heads * (double)o.Nq * o.Nk * o.D;
