@@ -8,8 +8,10 @@
 // LDS for a whole channel slice; the nine taps read it at shifted addresses.  Per slice that is
 // <= 56 KiB of X once plus 9 x 20 KiB of W for 256 rows: 2.8x fewer fill bytes per flop.
 //
-//   LDS: 2 halo buffers (slice s / s+1) x 448 slots x 128 B + 2 W stages x 160 rows x 128 B = 152 KiB,
-//        one workgroup of 8 waves (4 along pixels x 2 along channels) per CU.
+//   LDS: 2 halo buffers (slice s / s+1) x 400 slots x 128 B + 3 W stages x 160 rows x 128 B = 160 KiB exactly,
+//        one persistent workgroup of 8 waves (4 along pixels x 2 along channels) per CU.  W runs two K tiles
+//        ahead (counted vmcnt): inside a UNet forward the weights come cold from HBM, and with one tile of
+//        lead every K tile waited for them (3x3 conv time per forward 5.89 -> 5.61 ms).
 //   Slots and W rows hold their eight 16-B chunks XOR-swizzled by (slot & 7) / (row & 7), applied to
 //   the per-lane SOURCE address of the LDS-DMA; a fragment read of 16 consecutive pixels is then
 //   bank-conflict free for every tap shift.
@@ -26,13 +28,13 @@ namespace {
 constexpr int BM = 256, BN = 160;
 constexpr int TM = 4, TN = 5;                 // 16x16 tiles per wave: 64 pixels x 80 channels
 constexpr int WTM = 64, WTN = 80;
-constexpr int HSLOTS = 448;                   // 7 DMA pieces of 64 slots
-constexpr int HPIECES = HSLOTS * 8 / 512;
+constexpr int HSLOTS = 400;                   // 50 one-KiB DMA pieces; every wave issues 7 (6 of the 56 are re-issues)
+constexpr int HPIECES = 7;
 constexpr int HBYTES = HSLOTS * 128;
-constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage ...
-constexpr int WPIECES_PAD = 24;               // ... padded to 3 per wave: the K loop stays branch-free
-constexpr int WBYTES = WPIECES_PAD * 1024;
-constexpr int SMEM = 2 * HBYTES + 2 * WBYTES;
+constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage; every wave issues 3 (4 re-issues)
+constexpr int WBYTES = WPIECES * 1024;
+constexpr int WSTAGES = 3;                    // W(kt+1) may still be in flight while tile kt is multiplied
+constexpr int SMEM = 2 * HBYTES + WSTAGES * WBYTES;   // = 160 KiB exactly
 static_assert(SMEM <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
 constexpr unsigned NOSRC = 0xffffffffu;
 
@@ -85,9 +87,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     const int lgW = __builtin_ctz(Wo), lgHW = __builtin_ctz(HWo);
     const int RWin = RW >> up;                   // input rows under one piece
     int hrel[HPIECES];
+    // The 50 halo pieces do not divide over 8 waves x 7: waves >= 2 re-issue their piece 5 as piece 6 (same source,
+    // same LDS destination -- harmless), so that every wave issues the same number of DMAs and the counted
+    // vmcnt waits of the K loop are compile-time constants.
+    const int jdup = wave < 2 ? 6 : 5;
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) {
-        const int L = j * 512 + tid;
+        const int L = (j == 6 ? jdup : j) * 512 + tid;
         const int slot = L >> 3, cpos = L & 7;
         const int i = slot / PP, rem = slot - i * PP;
         const int hy = rem / PW, hx = rem - hy * PW;
@@ -96,6 +102,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                         (hy == 0 ? 4 : 0) | (hy == RWin + 1 ? 8 : 0))
                      : HREL_ZERO;
     }
+
+    // W stage pieces: wave w issues pieces w, w + 8 and w + 16; waves 4-7 have no third piece and re-issue w + 8
+    auto wpiece = [&](int i) { return i < 2 ? wave + 8 * i : (wave < 4 ? wave + 16 : wave + 8); };
 
     // ---- per-item state: tile origin, K range, source offsets -------------------------------------------
     int split = 0, m0 = 0, n0 = 0, s_begin = 0, s_end = 0;
@@ -121,20 +130,19 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int pc = wave + i * 8;
+            const int pc = wpiece(i);
             const int n = n0 + pc * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (lane >> 3);
-            woffs[i] = (pc < WPIECES && n < p.N) ? (unsigned)((long)n * p.ldw * 2 + (c << 4)) : NOSRC;
+            woffs[i] = n < p.N ? (unsigned)((long)n * p.ldw * 2 + (c << 4)) : NOSRC;
         }
     };
     auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch (zero page), keeps the loop branch-free
         const void* src = (hoff[j] != NOSRC && s >= 0) ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
-        glds16(src, hb + j * 8192 + wave * 1024);
+        glds16(src, hb + (j == 6 ? jdup : j) * 8192 + wave * 1024);
     };
     auto issue_w1 = [&](int i, int kk, char* wb) {   // kk = slice * 9 + tap; < 0: nothing to fetch
-        const int pc = wave + i * 8;                  // pieces 20..23 are padding (zero page -> unused LDS)
         const void* src = (woffs[i] != NOSRC && kk >= 0) ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
-        glds16(src, wb + pc * 1024);
+        glds16(src, wb + wpiece(i) * 1024);
     };
     auto issue_w = [&](int kk, char* wb) {
 #pragma unroll
@@ -167,17 +175,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
 
     char* const Hb0 = smem;
     char* const Hb1 = smem + HBYTES;
-    char* const Wb0 = smem + 2 * HBYTES;
-    char* const Wb1 = Wb0 + WBYTES;
+    char* const Wb = smem + 2 * HBYTES;          // WSTAGES stages of WBYTES
 
     // Buffer parities run on across items: the halo buffer / W stage an item starts in is the one its
     // predecessor was not reading in its last K tile, so the next item's first halo and W stage can be in
     // flight under the predecessor's epilogue stores.
-    int hsel = 0, wsel = 0;
+    int hsel = 0, wst = 0;                        // halo buffer / W stage of the tile about to be multiplied
     setup(work);
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, Hb0);
-    issue_w(s_begin * 9, Wb0);
+    issue_w(s_begin * 9, Wb);
+    issue_w(s_begin * 9 + 1, Wb + WBYTES);        // every item has >= 9 K tiles
     bool stores_pending = false;                  // exactly FULL_STORES stores were issued after that DMA
     constexpr int FULL_STORES = (TN / 2 + TN % 2) * TM;
 
@@ -193,16 +201,23 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             const bool more = s + 1 < s_end;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                // Everything issued one K tile ago has landed; every wave is done reading the buffers that
-                // are refilled below (W stage of tile kt-1, halo of slice s-1).  vmcnt counts stores too and
-                // retires in order: on an item's first tile a COUNTED wait leaves the predecessor's epilogue
-                // stores, issued after this tile's DMA, in flight.
-                if (tap == 0 && s == s_begin && stores_pending) wait_vmcnt<FULL_STORES>();
-                else wait_vmcnt<0>();
+                // In-order vmcnt: tile kt's W stage (issued two K tiles ago) and, at tap 0, the slice's halo have
+                // landed once only the DMAs of the PREVIOUS iteration -- its halo piece, if any, and the 3 pieces of
+                // W(kt+1) -- may still be pending; on an item's first tile also the predecessor's epilogue stores,
+                // which were issued after this item's prologue DMA.  After the barrier every wave is done reading
+                // the W stage of tile kt-1 and the halo of slice s-1, which are refilled below.
+                if (tap == 0) {
+                    if (s == s_begin && stores_pending) wait_vmcnt<3 + FULL_STORES>();
+                    else wait_vmcnt<3>();
+                } else if (tap == 8) {
+                    wait_vmcnt<3>();
+                } else {
+                    wait_vmcnt<4>();
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                const char* wcur = wsel ? Wb1 : Wb0;
-                char* wnext = wsel ? Wb0 : Wb1;
+                const char* wcur = Wb + wst * WBYTES;
+                char* wnext = Wb + (wst == 0 ? 2 : wst - 1) * WBYTES;      // stage of tile kt+2 = stage of tile kt-1
                 int xa[TM];
 #pragma unroll
                 for (int f = 0; f < TM; ++f) {
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
-                issue_w(tap < 8 ? s * 9 + tap + 1 : (more ? (s + 1) * 9 : -1), wnext);
+                issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
@@ -223,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
                 mfmas(xf0, wf0);
                 mfmas(xf1, wf1);
-                wsel ^= 1;
+                wst = wst == 2 ? 0 : wst + 1;
             }
             hsel ^= 1;
         }
@@ -272,10 +287,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             setup(work);
             // The buffers refilled here were last read one slice / one K tile before the final one, i.e.
             // before a barrier every wave has passed: no extra barrier.
+            // the two W stages refilled here received zero-page fills in this item's last two iterations: retire
+            // them first (two DMAs to one LDS address must not be in flight together)
+            wait_vmcnt<0>();
             char* hb = hsel ? Hb1 : Hb0;
 #pragma unroll
             for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, hb);
-            issue_w(s_begin * 9, wsel ? Wb1 : Wb0);
+            issue_w(s_begin * 9, Wb + wst * WBYTES);
+            issue_w(s_begin * 9 + 1, Wb + (wst == 2 ? 0 : wst + 1) * WBYTES);
             stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N);
         }
 
