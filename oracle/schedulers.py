@@ -199,15 +199,23 @@ class DPMSolverOracle(_Base):
             out.append((a, st, torch.log(a) - torch.log(st)))
         return out
 
-    def dpm_solver_first_order_update(self, model_output, sample):
+    def dpm_solver_first_order_update(self, model_output, sample, noise=None):
         (alpha_t, sigma_t, lambda_t), (alpha_s, sigma_s, lambda_s) = self._lambdas(
             self.sigmas[self.step_index + 1], self.sigmas[self.step_index])
         h = lambda_t - lambda_s
-        if self.config["algorithm_type"] == "dpmsolver++":
+        alg = self.config["algorithm_type"]
+        if alg == "dpmsolver++":
             return (sigma_t / sigma_s) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * model_output
-        return (alpha_t / alpha_s) * sample - (sigma_t * (torch.exp(h) - 1.0)) * model_output
+        if alg == "dpmsolver":
+            return (alpha_t / alpha_s) * sample - (sigma_t * (torch.exp(h) - 1.0)) * model_output
+        if alg == "sde-dpmsolver++":     # diffusers 0.32.1 DPMSolverMultistepScheduler [upstream-recall]
+            return ((sigma_t / sigma_s * torch.exp(-h)) * sample + (alpha_t * (1 - torch.exp(-2.0 * h))) * model_output
+                    + sigma_t * torch.sqrt(1.0 - torch.exp(-2.0 * h)) * noise)
+        assert alg == "sde-dpmsolver"
+        return ((alpha_t / alpha_s) * sample - 2.0 * (sigma_t * (torch.exp(h) - 1.0)) * model_output
+                + sigma_t * torch.sqrt(torch.exp(2.0 * h) - 1.0) * noise)
 
-    def multistep_dpm_solver_second_order_update(self, model_output_list, sample):
+    def multistep_dpm_solver_second_order_update(self, model_output_list, sample, noise=None):
         (alpha_t, sigma_t, lambda_t), (alpha_s0, sigma_s0, lambda_s0), (_, _, lambda_s1) = self._lambdas(
             self.sigmas[self.step_index + 1], self.sigmas[self.step_index], self.sigmas[self.step_index - 1])
         m0, m1 = model_output_list[-1], model_output_list[-2]
@@ -215,13 +223,22 @@ class DPMSolverOracle(_Base):
         r0 = h_0 / h
         D0, D1 = m0, (1.0 / r0) * (m0 - m1)
         assert self.config["solver_type"] == "midpoint"
-        if self.config["algorithm_type"] == "dpmsolver++":
+        alg = self.config["algorithm_type"]
+        if alg == "dpmsolver++":
             return ((sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0
                     - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
-        return ((alpha_t / alpha_s0) * sample - (sigma_t * (torch.exp(h) - 1.0)) * D0
-                - 0.5 * (sigma_t * (torch.exp(h) - 1.0)) * D1)
+        if alg == "dpmsolver":
+            return ((alpha_t / alpha_s0) * sample - (sigma_t * (torch.exp(h) - 1.0)) * D0
+                    - 0.5 * (sigma_t * (torch.exp(h) - 1.0)) * D1)
+        if alg == "sde-dpmsolver++":
+            return ((sigma_t / sigma_s0 * torch.exp(-h)) * sample + (alpha_t * (1 - torch.exp(-2.0 * h))) * D0
+                    + 0.5 * (alpha_t * (1 - torch.exp(-2.0 * h))) * D1
+                    + sigma_t * torch.sqrt(1.0 - torch.exp(-2.0 * h)) * noise)
+        assert alg == "sde-dpmsolver"
+        return ((alpha_t / alpha_s0) * sample - 2.0 * (sigma_t * (torch.exp(h) - 1.0)) * D0
+                - (sigma_t * (torch.exp(h) - 1.0)) * D1 + sigma_t * torch.sqrt(torch.exp(2.0 * h) - 1.0) * noise)
 
-    def multistep_dpm_solver_third_order_update(self, model_output_list, sample):
+    def multistep_dpm_solver_third_order_update(self, model_output_list, sample, noise=None):
         (alpha_t, sigma_t, lambda_t), (alpha_s0, sigma_s0, lambda_s0), (_, _, lambda_s1), (_, _, lambda_s2) = \
             self._lambdas(self.sigmas[self.step_index + 1], self.sigmas[self.step_index],
                           self.sigmas[self.step_index - 1], self.sigmas[self.step_index - 2])
@@ -232,16 +249,23 @@ class DPMSolverOracle(_Base):
         D1_0, D1_1 = (1.0 / r0) * (m0 - m1), (1.0 / r1) * (m1 - m2)
         D1 = D1_0 + (r0 / (r0 + r1)) * (D1_0 - D1_1)
         D2 = (1.0 / (r0 + r1)) * (D1_0 - D1_1)
-        if self.config["algorithm_type"] == "dpmsolver++":
+        alg = self.config["algorithm_type"]
+        if alg == "dpmsolver++":
             return ((sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0
                     + (alpha_t * ((torch.exp(-h) - 1.0) / h + 1.0)) * D1
                     - (alpha_t * ((torch.exp(-h) - 1.0 + h) / h ** 2 - 0.5)) * D2)
+        if alg == "sde-dpmsolver++":
+            return ((sigma_t / sigma_s0 * torch.exp(-h)) * sample + (alpha_t * (1.0 - torch.exp(-2.0 * h))) * D0
+                    + (alpha_t * ((1.0 - torch.exp(-2.0 * h)) / (-2.0 * h) + 1.0)) * D1
+                    + (alpha_t * ((1.0 - torch.exp(-2.0 * h) - 2.0 * h) / (2.0 * h) ** 2 - 0.5)) * D2
+                    + sigma_t * torch.sqrt(1.0 - torch.exp(-2.0 * h)) * noise)
+        assert alg == "dpmsolver", "sde-dpmsolver has no third-order update upstream"
         return ((alpha_t / alpha_s0) * sample - (sigma_t * (torch.exp(h) - 1.0)) * D0
                 - (sigma_t * ((torch.exp(h) - 1.0) / h - 1.0)) * D1
                 - (sigma_t * ((torch.exp(h) - 1.0 - h) / h ** 2 - 0.5)) * D2)
 
     # src/schedulers.py:98-187
-    def step(self, model_output, timestep, sample, generator=None, return_dict=False):
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=False):
         if self.step_index is None:
             self._init_step_index(timestep)
         n = len(self.timesteps)
@@ -256,13 +280,20 @@ class DPMSolverOracle(_Base):
             self.model_outputs[i] = self.model_outputs[i + 1]
         self.model_outputs[-1] = model_output
         sample = sample.to(torch.float32)
+        # src/schedulers.py:134-147
+        if self.config["algorithm_type"] in ["sde-dpmsolver", "sde-dpmsolver++"] and variance_noise is None:
+            noise = torch.randn(model_output.shape, generator=generator, dtype=torch.float32)
+        elif self.config["algorithm_type"] in ["sde-dpmsolver", "sde-dpmsolver++"]:
+            noise = variance_noise.to(dtype=torch.float32)
+        else:
+            noise = None
         so = self.config["solver_order"]
         if so == 1 or self.lower_order_nums < 1 or lower_order_final:
-            prev_sample = self.dpm_solver_first_order_update(model_output, sample=sample)
+            prev_sample = self.dpm_solver_first_order_update(model_output, sample=sample, noise=noise)
         elif so == 2 or self.lower_order_nums < 2 or lower_order_second:
-            prev_sample = self.multistep_dpm_solver_second_order_update(self.model_outputs, sample=sample)
+            prev_sample = self.multistep_dpm_solver_second_order_update(self.model_outputs, sample=sample, noise=noise)
         else:
-            prev_sample = self.multistep_dpm_solver_third_order_update(self.model_outputs, sample=sample)
+            prev_sample = self.multistep_dpm_solver_third_order_update(self.model_outputs, sample=sample, noise=noise)
         if self.lower_order_nums < so:
             self.lower_order_nums += 1
         self._step_index += 1

@@ -134,7 +134,8 @@ class _FusedStepScheduler:
              return_dict: bool = False, **kwargs):
         """Drop-in ``scheduler.step`` (CFG already combined by the caller, src/models.py:253)."""
         out_dtype = model_output.dtype
-        prev, x0 = self.step_fused(model_output, 0.0, sample, timestep, cfg=False, eta=eta, generator=generator)
+        kw = {"variance_noise": variance_noise} if variance_noise is not None else {}
+        prev, x0 = self.step_fused(model_output, 0.0, sample, timestep, cfg=False, eta=eta, generator=generator, **kw)
         return (prev.to(out_dtype), x0.to(out_dtype))
 
 
@@ -199,7 +200,9 @@ class DPMSolverScheduler(_FusedStepScheduler):
     Appendix-B quirk #2 of SURVEY.md: the reference unpacks two values from
     ``convert_model_output`` although its ``++`` branch returns one tensor; the intended behaviour
     implemented here is ``model_output := x0_pred`` for ``++`` and ``(epsilon, x0_pred)`` for
-    ``dpmsolver``.  SDE variants and thresholding are off the hot path.
+    ``dpmsolver``.  The SDE variants (``sde-dpmsolver`` / ``sde-dpmsolver++``, ``src/schedulers.py:134-147``)
+    add a Gaussian term through the kernel's noise coefficient: drawn from ``generator`` per step, or taken
+    from ``variance_noise``.  Thresholding is off the hot path.
     """
     _own_defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                          trained_betas=None, solver_order=2, prediction_type="epsilon", thresholding=False,
@@ -210,11 +213,11 @@ class DPMSolverScheduler(_FusedStepScheduler):
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
         c = self.config
-        if c.algorithm_type not in ("dpmsolver", "dpmsolver++"):
-            raise NotImplementedError(f"algorithm_type {c.algorithm_type}: SDE variants are off the hot path")
-        if c.algorithm_type == "dpmsolver" and c.final_sigmas_type == "zero":
-            raise ValueError("`final_sigmas_type` zero is not supported for `algorithm_type` dpmsolver. "
-                             "Please choose `sigma_min` instead.")
+        if c.algorithm_type not in ("dpmsolver", "dpmsolver++", "sde-dpmsolver", "sde-dpmsolver++"):
+            raise NotImplementedError(f"{c.algorithm_type} is not implemented for {self.__class__}")
+        if c.algorithm_type not in ("dpmsolver++", "sde-dpmsolver++") and c.final_sigmas_type == "zero":
+            raise ValueError(f"`final_sigmas_type` {c.final_sigmas_type} is not supported for `algorithm_type` "
+                             f"{c.algorithm_type}. Please choose `sigma_min` instead.")
         if c.solver_type != "midpoint" or c.prediction_type != "epsilon" or c.thresholding:
             raise NotImplementedError("only midpoint / epsilon / no thresholding is on the hot path")
         if c.solver_order not in (1, 2, 3):
@@ -266,9 +269,9 @@ class DPMSolverScheduler(_FusedStepScheduler):
     def _convert_coefs(self, i: int):
         a0, s0, _ = self._alpha_sigma_lambda(float(self.sigmas[i]))
         yx, ye = 1.0 / a0, -s0 / a0                       # x0 = (x - sigma_t eps) / alpha_t
-        if self.config.algorithm_type == "dpmsolver++":
+        if self.config.algorithm_type in ("dpmsolver++", "sde-dpmsolver++"):        # src/schedulers.py:35
             return yx, ye, yx, ye                         # history entry m := x0
-        return yx, ye, 0.0, 1.0                           # history entry m := eps
+        return yx, ye, 0.0, 1.0                           # history entry m := eps  (:64)
 
     def convert_model_output(self, model_output, *args, sample=None, **kwargs):
         """``src/schedulers.py:14-96``: returns (converted_output, x0_pred) at the current step."""
@@ -285,19 +288,32 @@ class DPMSolverScheduler(_FusedStepScheduler):
         return m, x0
 
     def _update_coefs(self, i: int, order: int, mx: float, me: float):
-        """prev = px*x + pe*eps + p1*m1 + p2*m2 for the order-`order` multistep update (A.6.2)."""
-        pp = self.config.algorithm_type == "dpmsolver++"
+        """prev = px*x + pe*eps + p1*m1 + p2*m2 + pn*z for the order-`order` multistep update (A.6.2); the SDE
+        variants (z ~ N(0, I)) use the same linear form with their own kA/kB/kC and a noise coefficient."""
+        alg = self.config.algorithm_type
+        pp = alg in ("dpmsolver++", "sde-dpmsolver++")
+        sde = alg.startswith("sde-")
         a_t, s_t, l_t = self._alpha_sigma_lambda(float(self.sigmas[i + 1]))
         a_0, s_0, l_0 = self._alpha_sigma_lambda(float(self.sigmas[i]))
         h = l_t - l_0
-        if pp:
+        pn = 0.0
+        if pp and not sde:
             ratio = s_t / s_0
             em1 = math.expm1(-h) if math.isfinite(h) else -1.0       # e^{-h} - 1
             kA = -a_t * em1
-        else:
+        elif not sde:
             ratio = a_t / a_0
             em1 = math.expm1(h)
             kA = -s_t * em1
+        elif pp:                                                     # sde-dpmsolver++
+            e2 = math.expm1(-2.0 * h) if math.isfinite(h) else -1.0   # e^{-2h} - 1
+            ratio = s_t / s_0 * (math.exp(-h) if math.isfinite(h) else 0.0)
+            kA = -a_t * e2
+            pn = s_t * math.sqrt(-e2)
+        else:                                                        # sde-dpmsolver
+            ratio = a_t / a_0
+            kA = -2.0 * s_t * math.expm1(h)
+            pn = s_t * math.sqrt(math.expm1(2.0 * h))
         c0, c1, c2 = kA, 0.0, 0.0
         if order >= 2:
             _, _, l_1 = self._alpha_sigma_lambda(float(self.sigmas[i - 1]))
@@ -308,7 +324,12 @@ class DPMSolverScheduler(_FusedStepScheduler):
         elif order == 3:
             _, _, l_2 = self._alpha_sigma_lambda(float(self.sigmas[i - 2]))
             r1 = (l_1 - l_2) / h
-            if pp:
+            if sde and not pp:
+                raise NotImplementedError("sde-dpmsolver has no third-order update (as upstream)")
+            if sde:
+                kB = a_t * (e2 / (2.0 * h) + 1.0)
+                kC = a_t * ((-e2 - 2.0 * h) / (4.0 * h * h) - 0.5)
+            elif pp:
                 kB = a_t * (em1 / h + 1.0)
                 kC = -a_t * ((em1 + h) / (h * h) - 0.5)
             else:
@@ -320,9 +341,10 @@ class DPMSolverScheduler(_FusedStepScheduler):
             c0 = kA + u / r0
             c1 = -u / r0 + v / r1
             c2 = -v / r1
-        return ratio + c0 * mx, c0 * me, c1, c2
+        return ratio + c0 * mx, c0 * me, c1, c2, pn
 
-    def step_fused(self, model_output, guidance_scale, sample, timestep, cfg=True, eta=0.0, generator=None):
+    def step_fused(self, model_output, guidance_scale, sample, timestep, cfg=True, eta=0.0, generator=None,
+                   variance_noise: Optional[torch.Tensor] = None):
         c = self.config
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
@@ -339,12 +361,19 @@ class DPMSolverScheduler(_FusedStepScheduler):
         else:
             order = 3
         yx, ye, mx, me = self._convert_coefs(i)
-        px, pe, p1, p2 = self._update_coefs(i, order, mx, me)
+        px, pe, p1, p2, pn = self._update_coefs(i, order, mx, me)
         hist = self.model_outputs                      # oldest ... newest
         m1 = hist[-1] if order >= 2 else None
         m2 = hist[-2] if order >= 3 else None
-        prev, x0, m0 = self._launch(self._prep(model_output), cfg, guidance_scale, self._prep(sample), m1, m2, None,
-                                    (px, pe, p1, p2, 0, yx, ye, mx, me), want_y2=True, want_m=True)
+        x = self._prep(sample)
+        z = None
+        if c.algorithm_type.startswith("sde-"):        # src/schedulers.py:134-147
+            if variance_noise is None:
+                gdev = generator.device if generator is not None else x.device
+                variance_noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=torch.float32)
+            z = self._prep(variance_noise.to(x.device))
+        prev, x0, m0 = self._launch(self._prep(model_output), cfg, guidance_scale, x, m1, m2, z,
+                                    (px, pe, p1, p2, pn, yx, ye, mx, me), want_y2=True, want_m=True)
         for k in range(c.solver_order - 1):
             self.model_outputs[k] = self.model_outputs[k + 1]
         self.model_outputs[-1] = m0

@@ -165,7 +165,11 @@ def test_ddim_host_coefficients_match_oracle():
 
 @pytest.mark.parametrize("algo,order,fst,n", [("dpmsolver++", 2, "zero", 20), ("dpmsolver++", 3, "zero", 6),
                                                ("dpmsolver++", 1, "zero", 4), ("dpmsolver", 2, "sigma_min", 10),
-                                               ("dpmsolver", 3, "sigma_min", 20), ("dpmsolver++", 2, "zero", 3)])
+                                               ("dpmsolver", 3, "sigma_min", 20), ("dpmsolver++", 2, "zero", 3),
+                                               # SDE variants (src/schedulers.py:134-147)
+                                               ("sde-dpmsolver++", 2, "zero", 20), ("sde-dpmsolver++", 1, "zero", 5),
+                                               ("sde-dpmsolver++", 3, "zero", 25), ("sde-dpmsolver++", 2, "sigma_min", 8),
+                                               ("sde-dpmsolver", 2, "sigma_min", 12), ("sde-dpmsolver", 1, "sigma_min", 6)])
 def test_dpm_host_coefficients_match_oracle(algo, order, fst, n):
     """The fused kernel's scalar coefficients reproduce the oracle's literal multistep update when
     applied with torch on CPU (same linear combination the kernel evaluates)."""
@@ -181,13 +185,15 @@ def test_dpm_host_coefficients_match_oracle(algo, order, fst, n):
     hist, lower = [], 0
     for i, t in enumerate(s._timesteps_list):
         e = torch.randn(128, generator=g, dtype=torch.float64)
-        ref_prev, ref_x0 = o.step(e.float(), t, x.float())
+        z = torch.randn(128, generator=g, dtype=torch.float64)
+        ref_prev, ref_x0 = o.step(e.float(), t, x.float(), variance_noise=z.float() if algo.startswith("sde") else None)
         lof = (i == n - 1) and ((n < 15) or fst == "zero")
         los = (i == n - 2) and n < 15
         k = 1 if (order == 1 or lower < 1 or lof) else (2 if (order == 2 or lower < 2 or los) else 3)
         yx, ye, mx, me = s._convert_coefs(i)
-        px, pe, p1, p2 = s._update_coefs(i, k, mx, me)
-        prev = px * x + pe * e + (p1 * hist[-1] if k >= 2 else 0) + (p2 * hist[-2] if k >= 3 else 0)
+        px, pe, p1, p2, pn = s._update_coefs(i, k, mx, me)
+        assert (pn != 0.0) == (algo.startswith("sde") and float(s.sigmas[i + 1]) > 0)
+        prev = px * x + pe * e + (p1 * hist[-1] if k >= 2 else 0) + (p2 * hist[-2] if k >= 3 else 0) + pn * z
         assert torch.allclose(prev.float(), ref_prev, rtol=3e-4, atol=3e-4), (i, k)
         assert torch.allclose((yx * x + ye * e).float(), ref_x0, rtol=3e-4, atol=3e-3), i
         hist.append(mx * x + me * e)

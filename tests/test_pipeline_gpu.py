@@ -42,6 +42,9 @@ def _sched(model, name, **kw):
     ("dpm", dict(solver_order=2, algorithm_type="dpmsolver++", final_sigmas_type="zero"), 20),
     ("dpm", dict(solver_order=3, algorithm_type="dpmsolver++", final_sigmas_type="zero"), 7),
     ("dpm", dict(solver_order=2, algorithm_type="dpmsolver", final_sigmas_type="sigma_min"), 10),
+    ("dpm", dict(solver_order=2, algorithm_type="sde-dpmsolver++", final_sigmas_type="zero"), 10),   # src/schedulers.py:134-147
+    ("dpm", dict(solver_order=3, algorithm_type="sde-dpmsolver++", final_sigmas_type="zero"), 20),
+    ("dpm", dict(solver_order=2, algorithm_type="sde-dpmsolver", final_sigmas_type="sigma_min"), 8),
     ("lcm", {}, 4),
     ("pndm", {}, 8),
 ])
@@ -65,6 +68,9 @@ def test_scheduler_step_matches_oracle(kind, kw, n):
         if kind == "lcm" and i < n - 1:
             z = torch.randn(2, 4, 16, 16, generator=g)
             kwo["noise"], kws["noise"] = z, z.cuda()
+        if kw.get("algorithm_type", "").startswith("sde-"):
+            z = torch.randn(2, 4, 16, 16, generator=g)
+            kwo["variance_noise"], kws["variance_noise"] = z, z.cuda()
         so = o.step(eo, t, xo, **kwo)
         sg = s.step_fused(e2.cuda(), 7.5, x.cuda(), int(t), cfg=True, **kws)
         assert len(so) == len(sg)
