@@ -3,7 +3,13 @@
 ``torch.Generator`` that is never reseeded, scheduler swap through the registry +
 ``from_config``, ``generate()`` looping prompt batches through ``self.model(...)`` and feeding
 ``time_metric``.  Quality metrics that need fetched models and the wandb logger are out of the
-hot-path scope; results go to stdout as JSON lines."""
+hot-path scope; results go to stdout as JSON lines.
+
+Multi-GPU (new relative to the single-device reference): launched under
+``torch.distributed.run`` (one process per GPU), every prompt batch is split contiguously over the ranks,
+each rank samples its shard on its own weight replica, and ONE all-gather per batch returns the results to
+every rank.  The global initial latents (and the LCM step noise) come from the shared seeded CPU generator and
+are sliced per rank, so the inputs of every image are the same for every world size."""
 from __future__ import annotations
 
 import json
@@ -12,6 +18,7 @@ from collections import defaultdict
 
 import torch
 
+from .. import dist as sdist
 from ..dataset import PromptDataset
 from ..registry import metrics_registry, models_registry, schedulers_registry
 
@@ -19,7 +26,15 @@ from ..registry import metrics_registry, models_registry, schedulers_registry
 class BaseMethod(ABC):
     def __init__(self, config):
         self.config = config
-        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        # one process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE); world 1 otherwise.
+        # SD_DIST_BACKEND=gloo is the CPU-side rehearsal backend of the tests (ranks may then share one GPU)
+        import os
+        backend = os.environ.get("SD_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        self.rank, local_rank, self.world = sdist.init_process_group(backend)
+        ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        self.device = f"cuda:{local_rank % ngpu}" if ngpu else "cpu"
+        if ngpu:
+            torch.cuda.set_device(self.device)
         self.setup_exp_params()
         self.setup_generator()
         self.setup_model()
@@ -73,17 +88,53 @@ class BaseMethod(ABC):
         if steps is not None:
             call_kwargs["num_inference_steps"] = steps
         limit = self.config.inference.get("batch_count", None)
-        out_type = self.config.inference.get("output_type", "latent")
+        out_type = self.config.inference.get("output_type", "pt")        # the reference hard-codes "pt" (:145)
         images, x0_preds = [], []
         for idx, batch in enumerate(test_dataloader):
             if limit is not None and idx >= limit:
                 break
-            result, seconds, x0_preds = self.model(batch["prompt"], guidance_scale=guidance_scale,
-                                                   generator=self.generator, output_type=out_type, **call_kwargs)
-            host = result.images.cpu()
+            prompts = list(batch["prompt"])
+            kw = dict(call_kwargs)
+            if self.world > 1:
+                lo, hi = sdist.shard_range(len(prompts), self.rank, self.world)
+                kw.update(self._global_draws(len(prompts), lo, hi, kw))
+                local_prompts = prompts[lo:hi]
+            else:
+                local_prompts = prompts
+            if len(local_prompts) > 0:
+                result, seconds, x0_preds = self.model(local_prompts, guidance_scale=guidance_scale,
+                                                       generator=self.generator, output_type=out_type, **kw)
+                local = result.images
+            else:                       # more ranks than prompts in a ragged last batch
+                local, seconds = self._empty_result(out_type), 0.0
+            if self.world > 1:          # the ONE data-path collective; the slowest rank's loop time rides along
+                local, seconds = sdist.gather_latents(local, self.world, len(prompts), seconds=seconds)
+            host = local.cpu()
             images.extend(host[i] for i in range(host.shape[0]))
             self.time_metric.update(seconds, batch_size)                 # configured size, as :161
         return images, x0_preds
+
+    def _global_draws(self, n: int, lo: int, hi: int, kw: dict) -> dict:
+        """Explicit ``latents=`` (and LCM ``step_noise=``) of this rank's shard, cut from the GLOBAL draws of the
+        shared generator -- in the order the single-process run consumes it: initial latents of the whole batch
+        (``prepare_latents``), then one Gaussian of the whole batch per re-noising step (``LCMScheduler.step``)."""
+        ucfg = self.model.unet_config
+        shape = (n, ucfg.in_channels, ucfg.sample_size, ucfg.sample_size)
+        lat = torch.randn(shape, generator=self.generator, dtype=torch.float32)
+        out = {"latents": lat[lo:hi].clone()}
+        sch = self.model.scheduler
+        steps = kw.get("num_inference_steps")
+        if hasattr(sch, "config") and "timestep_scaling" in sch.config and steps:
+            noise = [torch.randn(shape, generator=self.generator, dtype=torch.float32)[lo:hi] for _ in range(steps - 1)]
+            if noise:
+                out["step_noise"] = torch.stack(noise).to(self.device)
+        return out
+
+    def _empty_result(self, out_type: str) -> torch.Tensor:
+        ucfg = self.model.unet_config
+        if out_type == "latent":
+            return torch.empty((0, ucfg.in_channels, ucfg.sample_size, ucfg.sample_size), device=self.device)
+        return torch.empty((0, 3, ucfg.sample_size * 8, ucfg.sample_size * 8), device=self.device)
 
     def sweep(self, points, call_kwargs, label, extra=None, guidance_scale: float = 7.5):
         """The loop every method's ``run_experiment`` is: for each sweep point move the model to the device,
@@ -108,7 +159,10 @@ class BaseMethod(ABC):
         t = float(self.time_metric.compute())
         self.metric_dict["nfe"].append(self.model.num_timesteps)
         self.metric_dict["time_metric"].append(t)
+        self.time_metric.reset()
+        if self.rank != 0:
+            return
         print(json.dumps({"experiment": self.config.experiment_name, "run": name_images, "nfe": self.model.num_timesteps,
                           "images": n_images, "time_metric_s_per_image": t,
-                          "images_per_s": (1.0 / t if t > 0 else None), "weights": self.model.weights_source}), flush=True)
-        self.time_metric.reset()
+                          "images_per_s": (1.0 / t if t > 0 else None), "weights": self.model.weights_source,
+                          "n_gpus": self.world}), flush=True)

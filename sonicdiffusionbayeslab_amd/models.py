@@ -118,8 +118,10 @@ class StableDiffusionModel:
                 if item[0] == "file":
                     from .weights import fuse_lora_state_dict
                     fuse_lora_state_dict(sd, item[1], item[2])
+                    self.weights_source += " + LoRA(local file) fused"
                 else:
                     _fuse_synthetic_lora(sd, *item)
+                    self.weights_source += f" + SYNTHETIC low-rank stand-in for a hub LoRA (seed={item[0]}) fused"
             self.unet = HipUNet2DConditionModel(self.unet_config, sd, device="cuda:%d" % torch.cuda.current_device())
             self._state_dict = None
 

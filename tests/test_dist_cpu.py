@@ -1,4 +1,6 @@
-"""CPU: the N>1 path (batch shard + ONE all-gather of final latents) with world_size 2 over gloo."""
+"""CPU: the N>1 path (batch shard + ONE all-gather of final latents) with world_size 2 over gloo --
+the collective itself, and the harness (`BaseMethod.generate`) sharding prompt batches around a stub
+pipeline (the real pipeline needs the GPU: tests/test_dist_gpu.py)."""
 import os
 import socket
 
@@ -42,3 +44,101 @@ def test_gather_equals_single_process_even_and_ragged():
         outs = _run(gb)
         want = global_latents(gb, 4, 8, seed=29) * 2.0 + 1.0
         assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BaseMethod.generate under 2 ranks: shard -> per-rank pipeline call -> ONE gather (stub pipeline on CPU)
+# ---------------------------------------------------------------------------------------------------
+class _StubOut:
+    def __init__(self, images):
+        self.images = images
+
+
+class _StubPipeline:
+    """Deterministic per-image function of (prompt, initial latent, LCM noise): what a sampler is to the harness."""
+    weights_source = "stub"
+    num_timesteps = 3
+
+    def __init__(self, lcm):
+        from sonicdiffusionbayeslab_amd.weights import UNetConfig
+        from sonicdiffusionbayeslab_amd.schedulers import SchedulerConfig
+        self.unet_config = UNetConfig(sample_size=8)
+        self.scheduler = type("S", (), {})()
+        self.scheduler.config = SchedulerConfig(timestep_scaling=10.0) if lcm else SchedulerConfig()
+        self.calls = []
+
+    def to(self, device):
+        return self
+
+    def __call__(self, prompts, num_inference_steps=3, guidance_scale=7.5, generator=None, output_type="latent",
+                 latents=None, step_noise=None, **kw):
+        n = len(prompts)
+        if latents is None:
+            latents = torch.randn((n, 4, 8, 8), generator=generator)
+        out = latents.clone()
+        lcm = "timestep_scaling" in self.scheduler.config
+        for i in range(num_inference_steps - 1 if lcm else 0):
+            z = step_noise[i].cpu() if step_noise is not None else torch.randn((n, 4, 8, 8), generator=generator)
+            out = out * 0.5 + z
+        key = torch.tensor([float(sum(map(ord, p)) % 97) for p in prompts]).view(n, 1, 1, 1)
+        self.calls.append(n)
+        return _StubOut(out + key), 0.25 + 0.01 * n, [out[0:1]]
+
+
+def _harness_worker(rank, world, port, lcm, nprompts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SD_DIST_BACKEND="gloo")
+    q.put((rank,) + _harness_run(lcm, nprompts))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _harness_run(lcm, nprompts):
+    from sonicdiffusionbayeslab_amd.config import _wrap
+    from sonicdiffusionbayeslab_amd.experiments.base_experiment import BaseMethod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    class M(BaseMethod):
+        def setup_model(self):
+            self.model = _StubPipeline(lcm)
+
+        def setup_scheduler(self, **kw):
+            pass
+
+        def run_experiment(self):
+            pass
+
+    conf = _wrap({"experiment_name": "stub", "experiment": {"method": "stub", "seed": 29},
+                  "dataset": {"img_dataset": "", "prompts": os.path.join(root, "data", "dataset", "img2annotations_test.json")},
+                  "inference": {"batch_size": 5, "batch_count": (nprompts + 4) // 5, "output_type": "latent"}})
+    m = M(conf)
+    m.test_dataset.image_files = m.test_dataset.image_files[:nprompts]
+    images, _ = m.generate(m.test_dataset.batches(5), 3, 5, guidance_scale=0.0 if lcm else 7.5)
+    return torch.stack(images), float(m.time_metric.compute()), list(m.model.calls)
+
+
+def _harness_world2(lcm, nprompts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_harness_worker, args=(r, 2, port, lcm, nprompts, q)) for r in range(2)]
+    [p.start() for p in ps]
+    outs = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    return outs
+
+
+def test_generate_shards_batches_and_gathers_like_single_process():
+    for lcm, nprompts in ((False, 10), (True, 7), (False, 6)):      # even split, ragged batches, a rank with 0 prompts
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        want, t1, calls1 = _harness_run(lcm, nprompts)              # world 1, this process
+        outs = _harness_world2(lcm, nprompts)
+        for r in (0, 1):
+            got, t2, calls = outs[r]
+            assert torch.equal(got, want), (lcm, nprompts, r)
+            assert sum(calls) + sum(outs[1 - r][2]) == nprompts
+        # the slowest rank's loop time is what every rank accumulates
+        assert outs[0][1] == outs[1][1] and outs[0][1] <= t1

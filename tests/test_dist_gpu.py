@@ -1,0 +1,78 @@
+"""GPU: the product's N>1 path end to end -- two ranks (gloo rendezvous, both on cuda:0: one-GPU box), the real
+pipeline on a tiny UNet, prompt batches sharded inside ``BaseMethod.generate`` and gathered by ONE collective --
+against the same harness run as a single process.
+
+Tolerance: the inputs of every image are bit-identical for every world size (global draws from the shared CPU
+generator); outputs agree to rel-L2 <= 5e-3, not bit for bit, because the split-K factors of the GEMM / conv kernels
+depend on the per-rank UNet batch (fp32 partial sums are grouped differently before the bf16 rounding)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SHARD_TOL = 5e-3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_method(config_name, nprompts, batch):
+    """`methods_registry[...]` from its YAML on a 16x16-latent SD-1.5-width UNet; returns gathered latents."""
+    from sonicdiffusionbayeslab_amd import models as M
+    from sonicdiffusionbayeslab_amd.config import load_config
+    from sonicdiffusionbayeslab_amd.registry import methods_registry
+    from sonicdiffusionbayeslab_amd.weights import UNetConfig, make_synthetic_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.chdir(root)
+    ucfg = UNetConfig(sample_size=16)
+    sd = make_synthetic_state_dict(ucfg, seed=1234)
+    M.StableDiffusionModel.from_pretrained = classmethod(
+        lambda c, *a, **k: c(unet_config=ucfg, state_dict=dict(sd), source="synthetic(seed=1234) tiny"))
+    conf = load_config(os.path.join(root, "configs", config_name))
+    conf.inference.batch_size = batch
+    conf.inference.batch_count = (nprompts + batch - 1) // batch
+    conf.inference.output_type = "latent"
+    m = methods_registry[conf.experiment.method](conf)
+    m.test_dataset.image_files = m.test_dataset.image_files[:nprompts]
+    steps = 4
+    gs = getattr(m, "guidance_scale", 7.5)
+    m.model.to(m.device)
+    images, _ = m.generate(m.test_dataset.batches(batch), steps, batch, guidance_scale=gs)
+    return torch.stack(images), float(m.time_metric.compute())
+
+
+def _worker(rank, world, port, config_name, nprompts, batch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    out, t = _run_method(config_name, nprompts, batch)
+    q.put((rank, out.cpu(), t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config_name,nprompts,batch", [("ddim_config.yaml", 5, 5),                 # CFG, ragged 3 + 2
+                                                         ("consistency_model_config.yaml", 6, 4)])  # LCM noise, 2 batches
+def test_world2_sharded_generate_matches_single_process(config_name, nprompts, batch):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    want, t1 = _run_method(config_name, nprompts, batch)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, config_name, nprompts, batch, q)) for r in range(2)]
+    [p.start() for p in ps]
+    outs = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(2))}
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    from tests.util import rel_l2
+    assert torch.equal(outs[0][0], outs[1][0]), "both ranks must hold the same gathered batch"
+    err = rel_l2(outs[0][0], want)
+    print(f"{config_name}: world-2 vs world-1 rel-L2 {err:.3e} over {nprompts} images")
+    assert outs[0][0].shape == want.shape and err < SHARD_TOL
+    assert outs[0][1] > 0 and outs[0][1] == outs[1][1]

@@ -106,6 +106,7 @@ def test_variant_methods_run_from_yaml(env, tmp_path, monkeypatch):
         conf = load_config(os.path.join(root, "configs", name))
         conf.inference.batch_size = 2
         conf.inference.batch_count = 1
+        conf.inference.output_type = "latent"
         m = methods_registry[conf.experiment.method](conf)
         m.run_experiment()
         assert len(m.metric_dict["time_metric"]) >= 2 and all(t > 0 for t in m.metric_dict["time_metric"])
