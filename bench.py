@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (text encode + loop + VAE decode) report")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE configs[2..4] reported under other_configs (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -112,6 +114,10 @@ def end_to_end(model, args, dev):
     return best
 
 
+TRAFFIC_SOURCE = ("profiles/round1_conv_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                  "tools/run_traffic.sh; NOT measured in this run)")
+
+
 def conv_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/run_traffic.sh ->
     profiles/round1_conv_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the 50 conv launches of
@@ -125,38 +131,35 @@ def conv_traffic_bytes():
         return None
 
 
-def main():
-    args = parse()
-    from sonicdiffusionbayeslab_amd import dist as sdist
-    # SD_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N>1 code path (several ranks share cuda:0);
-    # the real run uses RCCL ("nccl"), one rank per GPU
-    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")
-    rank, local_rank, world = sdist.init_process_group(backend)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks with torch.distributed.run (one process
+    per GPU, RCCL).  Runs BEFORE this process has touched the GPU; the parent only waits and passes the exit code on."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
+
+def timed_runs(model, args_like, dev, rank, world, sdist):
+    """W warm-up + K timed sampling runs of one workload; returns (images/s, ms per run, loop seconds, final latents).
+    The timed region is bracketed by a barrier + device synchronisation on both sides, MAX over ranks."""
     from sonicdiffusionbayeslab_amd.deepcache import DeepCacheSDHelper
-    from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
     from sonicdiffusionbayeslab_amd.registry import schedulers_registry
-    from sonicdiffusionbayeslab_amd.weights import UNetConfig, make_synthetic_state_dict
-
-    cfg = UNetConfig(sample_size=args.sample_size)
-    sd = make_synthetic_state_dict(cfg, seed=1234)
-    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd), source="synthetic(seed=1234)")
-    model.to(dev)
-    name = {"ddim": "ddim_scheduler", "dpm": "dpm_solver_scheduler", "lcm": "lcm_scheduler"}[args.scheduler]
+    a = args_like
+    cfg = model.unet_config
+    name = {"ddim": "ddim_scheduler", "dpm": "dpm_solver_scheduler", "lcm": "lcm_scheduler"}[a.scheduler]
     model.scheduler = schedulers_registry[name].from_config(model.scheduler.config)
-    if args.cache_interval > 0:
-        h = DeepCacheSDHelper(pipe=model)
-        h.set_params(cache_interval=args.cache_interval, cache_branch_id=0)
-        h.enable()
-    guidance = 0.0 if args.scheduler == "lcm" else 7.5
-
-    # synthetic inputs, resident in HBM before the timed region; global draw sliced per rank
-    B = args.batch
+    helper = None
+    if a.cache_interval > 0:
+        helper = DeepCacheSDHelper(pipe=model)
+        helper.set_params(cache_interval=a.cache_interval, cache_branch_id=0)
+        helper.enable()
+    guidance = 0.0 if a.scheduler == "lcm" else 7.5
+    B = a.batch
     gb = B * world
     lo, hi = sdist.shard_range(gb, rank, world)
     lat_all = sdist.global_latents(gb, 4, cfg.sample_size, seed=29)
@@ -169,18 +172,18 @@ def main():
 
     def one_run():
         out, secs, _ = model(prompt_embeds=pe, negative_prompt_embeds=neg, latents=lat,
-                             num_inference_steps=args.ddim_steps, guidance_scale=guidance,
+                             num_inference_steps=a.ddim_steps, guidance_scale=guidance,
                              output_type="latent", collect_x0=False)
         return sdist.gather_latents(out.images, world, gb), secs
 
-    for _ in range(args.warmup):
+    for _ in range(a.warmup):
         one_run()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     loop_secs = 0.0
-    for _ in range(args.steps):
+    for _ in range(a.steps):
         final, secs = one_run()
         loop_secs += secs
     torch.cuda.synchronize()
@@ -188,18 +191,71 @@ def main():
         torch.distributed.barrier()
     elapsed = time.time() - t0
     if world > 1:
+        backend = torch.distributed.get_backend()
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(final).all(), "non-finite latents"
+    if helper is not None:
+        helper.disable()
+    return gb * a.steps / elapsed, 1e3 * elapsed / a.steps, loop_secs, lat, guidance
+
+
+def other_configs(model, args, dev, sdist):
+    """Short driver-visible runs of the other single-GPU-sized BASELINE configs (per-GPU batch of each):
+    configs[2] DPM-Solver++ 20 steps batch 32; configs[3] DeepCache N=3 on DDIM-50, 16/GPU; configs[4] LCM 4 steps,
+    32/GPU (bf16 weights here).  1 warm-up + 2 timed runs each; images/s on this one GPU."""
+    import types
+    out = []
+    for label, sched, steps, batch, interval in (
+            ("configs[2]: DPM-Solver++ (order 2) 20 steps, CFG 7.5, batch 32", "dpm", 20, 32, 0),
+            ("configs[3] per-GPU share: DeepCache N=3 branch 0, DDIM 50 steps, CFG 7.5, batch 16", "ddim", 50, 16, 3),
+            ("configs[4] per-GPU share: LCM 4 steps, no CFG, batch 32", "lcm", 4, 32, 0)):
+        a = types.SimpleNamespace(scheduler=sched, ddim_steps=steps, batch=batch, cache_interval=interval, steps=2, warmup=1)
+        ips, ms, loop_secs, _, _ = timed_runs(model, a, dev, 0, 1, sdist)
+        out.append({"workload": label, "value": ips, "unit": "images/s", "ms_per_step": ms, "steps": 2, "warmup": 1,
+                    "dtype": "bf16", "loop_only_s_per_image": loop_secs / (2 * batch)})
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    from sonicdiffusionbayeslab_amd import dist as sdist
+    # SD_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N>1 code path (several ranks share cuda:0);
+    # the real run uses RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")
+    rank, local_rank, world = sdist.init_process_group(backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
+    from sonicdiffusionbayeslab_amd.weights import UNetConfig, make_synthetic_state_dict
+
+    cfg = UNetConfig(sample_size=args.sample_size)
+    sd = make_synthetic_state_dict(cfg, seed=1234)
+    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd), source="synthetic(seed=1234)")
+    model.to(dev)
+    B = args.batch
+    gb = B * world
+    # synthetic inputs, resident in HBM before the timed region; global draw sliced per rank
+    value, ms_per_step, loop_secs, lat, guidance = timed_runs(model, args, dev, rank, world, sdist)
+    elapsed = ms_per_step * args.steps / 1e3
+    is_headline = (args.scheduler == "ddim" and args.ddim_steps == 50 and B == 8 and not args.cache_interval
+                   and args.sample_size == 64)
 
     res = {
         "metric": f"512x512 images/sec at {args.ddim_steps} {args.scheduler.upper()} steps",   # default: BASELINE's metric
-        "value": gb * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SD-1.5 512x512 {args.scheduler.upper()} {args.ddim_steps} steps, CFG {guidance}, "
-                               f"batch={B}/GPU (BASELINE configs[1])" + (f", DeepCache N={args.cache_interval}" if args.cache_interval else ""),
+                               f"batch={B}/GPU" + (" (BASELINE configs[1])" if is_headline else "")
+                               + (f", DeepCache N={args.cache_interval}" if args.cache_interval else ""),
                    "global_batch": gb, "sample_size": cfg.sample_size, "parallelism": f"batch-shard x{world}",
                    "weights": "SD-1.5-shaped synthetic seed 1234", "loop_only_s_per_image": loop_secs / (args.steps * B)},
     }
@@ -216,6 +272,7 @@ def main():
         res["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel (3x3 conv, LDS-resident input halo; 47 of the 50 conv launches of a forward)",
                            "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": conv_traffic_bytes(),
+                           "traffic_source": TRAFFIC_SOURCE,
                            "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
                            "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
         tot = sum(v["ms"] for v in prof.values())
@@ -224,6 +281,11 @@ def main():
                 "tflops": (round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] and v["ms"] else None),
                 "alg_GBs": (round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None)}
             for k, v in prof.items()}
+    if rank == 0 and world == 1 and is_headline and not args.no_other_configs:
+        res["other_configs"] = other_configs(model, args, dev, sdist)
+        args_sched = {"ddim": "ddim_scheduler", "dpm": "dpm_solver_scheduler", "lcm": "lcm_scheduler"}[args.scheduler]
+        from sonicdiffusionbayeslab_amd.registry import schedulers_registry
+        model.scheduler = schedulers_registry[args_sched].from_config(model.scheduler.config)
     if rank == 0 and world == 1 and not args.no_e2e and args.sample_size == 64:
         res["config"]["end_to_end"] = end_to_end(model, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -226,3 +226,35 @@ def test_prompt_strings_and_harness_call_shape(env):
     assert torch.equal(imgs.images, again.images)        # deterministic: same seed, same kernels
     with pytest.raises(NotImplementedError):
         model(["x"], num_inference_steps=1, output_type="pil")
+
+
+@pytest.mark.parametrize("name,runs", [("ddim_config.yaml", 8), ("dpm_solver_config.yaml", 7),
+                                        ("consistency_model_config.yaml", 7), ("deep_cache_config.yaml", 10)])
+def test_method_plugins_run_from_yaml(env, monkeypatch, capsys, name, runs):
+    """the four in-scope method plugins (src/experiments/{ddim,dpm_solver,consistency_model,
+    deep_cache}.py) run `run_experiment()` end to end from their shipped YAML -- the reference's own sweep lists --
+    through the registries (tiny UNet, one prompt batch of 2 per sweep point)."""
+    import json, os
+    from sonicdiffusionbayeslab_amd import models as M
+    from sonicdiffusionbayeslab_amd.config import load_config
+    from sonicdiffusionbayeslab_amd.registry import methods_registry
+    from sonicdiffusionbayeslab_amd.weights import UNetConfig
+    cfg, sd, _ = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(root)
+    monkeypatch.setattr(M.StableDiffusionModel, "from_pretrained",
+                        classmethod(lambda c, *a, **k: c(unet_config=UNetConfig(sample_size=16), state_dict=dict(sd))))
+    conf = load_config(os.path.join(root, "configs", name))
+    conf.inference.batch_size = 2
+    conf.inference.batch_count = 1
+    conf.inference.output_type = "latent"
+    m = methods_registry[conf.experiment.method](conf)
+    m.run_experiment()
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == runs, (len(lines), runs)
+    for rec in lines:
+        assert rec["images"] == 2 and rec["time_metric_s_per_image"] > 0 and rec["nfe"] >= 1
+    if name == "deep_cache_config.yaml":      # checkpoint scheduler (PNDM): N steps = N + 1 UNet calls
+        assert [r["nfe"] for r in lines[:5]] == [6, 11, 101, 501, 101]
+    if name == "consistency_model_config.yaml":
+        assert all("SYNTHETIC low-rank stand-in" in r["weights"] for r in lines)
