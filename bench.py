@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense (v_mfma_f32_16x16x128_f8f6f4)
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE_FWD = 803.3
 
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "dpm", "lcm"])
     ap.add_argument("--cache-interval", type=int, default=0, help="DeepCache interval (0 = off)")
     ap.add_argument("--sample-size", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="operand type of the UNet's conv / FF / QKV contractions (fp8 = e4m3 weights + activations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (text encode + loop + VAE decode) report")
@@ -152,7 +155,8 @@ def timed_runs(model, args_like, dev, rank, world, sdist):
     a = args_like
     cfg = model.unet_config
     name = {"ddim": "ddim_scheduler", "dpm": "dpm_solver_scheduler", "lcm": "lcm_scheduler"}[a.scheduler]
-    model.scheduler = schedulers_registry[name].from_config(model.scheduler.config)
+    from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
+    model.scheduler = schedulers_registry[name].from_config(PNDMConfigStub().config)   # the checkpoint's scheduler config
     helper = None
     if a.cache_interval > 0:
         helper = DeepCacheSDHelper(pipe=model)
@@ -201,7 +205,7 @@ def timed_runs(model, args_like, dev, rank, world, sdist):
     return gb * a.steps / elapsed, 1e3 * elapsed / a.steps, loop_secs, lat, guidance
 
 
-def other_configs(model, args, dev, sdist):
+def other_configs(model, args, dev, sdist, sd):
     """Short driver-visible runs of the other single-GPU-sized BASELINE configs (per-GPU batch of each):
     configs[2] DPM-Solver++ 20 steps batch 32; configs[3] DeepCache N=3 on DDIM-50, 16/GPU; configs[4] LCM 4 steps,
     32/GPU (bf16 weights here).  1 warm-up + 2 timed runs each; images/s on this one GPU."""
@@ -215,6 +219,25 @@ def other_configs(model, args, dev, sdist):
         ips, ms, loop_secs, _, _ = timed_runs(model, a, dev, 0, 1, sdist)
         out.append({"workload": label, "value": ips, "unit": "images/s", "ms_per_step": ms, "steps": 2, "warmup": 1,
                     "dtype": "bf16", "loop_only_s_per_image": loop_secs / (2 * batch)})
+    # configs[4] as BASELINE names it: fp8 MFMA weights (a second weight replica, e4m3 conv / FF / QKV contractions)
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
+    m8 = StableDiffusionModel(unet_config=model.unet_config, state_dict=dict(sd), source="synthetic(seed=1234)",
+                              weight_dtype="fp8").to(dev)
+    a = types.SimpleNamespace(scheduler="lcm", ddim_steps=4, batch=32, cache_interval=0, steps=2, warmup=1)
+    ips, ms, loop_secs, lat8, _ = timed_runs(m8, a, dev, 0, 1, sdist)
+    prof = m8.unet.forward_profiled(lat8, 32, 501.0)
+    prof = m8.unet.forward_profiled(lat8, 32, 501.0)
+    c8, g8 = prof["conv3x3_fp8"], prof["gemm_fp8"]
+    out.append({"workload": "configs[4] per-GPU share: LCM 4 steps, no CFG, batch 32, fp8-e4m3 weights + activations in the "
+                            "resnet conv / FF / QKV / proj_in contractions", "value": ips, "unit": "images/s",
+                "ms_per_step": ms, "steps": 2, "warmup": 1, "dtype": "fp8_e4m3", "loop_only_s_per_image": loop_secs / (2 * 32),
+                "roofline": {"bound": "mfma", "kernel": "conv_halo_kernel<fp8>", "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "achieved": c8["flops"] / (c8["ms"] * 1e-3) / 1e12,
+                             "frac": c8["flops"] / (c8["ms"] * 1e-3) / 1e12 / MFMA_FP8_PEAK_TFLOPS,
+                             "launches_per_forward": c8["launches"], "avg_launch_ms": c8["ms"] / max(c8["launches"], 1),
+                             "gemm_fp8_tflops": g8["flops"] / (g8["ms"] * 1e-3) / 1e12 if g8["ms"] else None}})
+    del m8
+    torch.cuda.empty_cache()
     return out
 
 
@@ -238,7 +261,7 @@ def main():
 
     cfg = UNetConfig(sample_size=args.sample_size)
     sd = make_synthetic_state_dict(cfg, seed=1234)
-    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd), source="synthetic(seed=1234)")
+    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd), source="synthetic(seed=1234)", weight_dtype=args.dtype)
     model.to(dev)
     B = args.batch
     gb = B * world
@@ -246,13 +269,14 @@ def main():
     value, ms_per_step, loop_secs, lat, guidance = timed_runs(model, args, dev, rank, world, sdist)
     elapsed = ms_per_step * args.steps / 1e3
     is_headline = (args.scheduler == "ddim" and args.ddim_steps == 50 and B == 8 and not args.cache_interval
-                   and args.sample_size == 64)
+                   and args.sample_size == 64 and args.dtype == "bf16")
+    dtype_name = "bf16" if args.dtype == "bf16" else "fp8_e4m3"
 
     res = {
         "metric": f"512x512 images/sec at {args.ddim_steps} {args.scheduler.upper()} steps",   # default: BASELINE's metric
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": f"SD-1.5 512x512 {args.scheduler.upper()} {args.ddim_steps} steps, CFG {guidance}, "
                                f"batch={B}/GPU" + (" (BASELINE configs[1])" if is_headline else "")
                                + (f", DeepCache N={args.cache_interval}" if args.cache_interval else ""),
@@ -267,12 +291,17 @@ def main():
     if rank == 0 and not args.no_roofline:
         prof = model.unet.forward_profiled(lat, ub, 501.0)       # warm
         prof = model.unet.forward_profiled(lat, ub, 501.0)
-        c3 = prof["conv3x3"]
+        fp8 = args.dtype == "fp8"
+        c3 = prof["conv3x3_fp8"] if fp8 else prof["conv3x3"]
+        peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS
         ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel (3x3 conv, LDS-resident input halo; 47 of the 50 conv launches of a forward)",
-                           "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": conv_traffic_bytes(),
-                           "traffic_source": TRAFFIC_SOURCE,
+        res["roofline"] = {"bound": "mfma",
+                           "kernel": ("conv_halo_kernel<fp8> (3x3 resnet convs on v_mfma_f32_16x16x128_f8f6f4, LDS-resident input halo)"
+                                      if fp8 else
+                                      "conv_halo_kernel (3x3 conv, LDS-resident input halo; 47 of the 50 conv launches of a forward)"),
+                           "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                           "frac": ach / peak, "traffic": None if fp8 else conv_traffic_bytes(),
+                           "traffic_source": None if fp8 else TRAFFIC_SOURCE,
                            "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
                            "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
         tot = sum(v["ms"] for v in prof.values())
@@ -282,10 +311,11 @@ def main():
                 "alg_GBs": (round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] else None)}
             for k, v in prof.items()}
     if rank == 0 and world == 1 and is_headline and not args.no_other_configs:
-        res["other_configs"] = other_configs(model, args, dev, sdist)
+        res["other_configs"] = other_configs(model, args, dev, sdist, sd)
         args_sched = {"ddim": "ddim_scheduler", "dpm": "dpm_solver_scheduler", "lcm": "lcm_scheduler"}[args.scheduler]
         from sonicdiffusionbayeslab_amd.registry import schedulers_registry
-        model.scheduler = schedulers_registry[args_sched].from_config(model.scheduler.config)
+        from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
+        model.scheduler = schedulers_registry[args_sched].from_config(PNDMConfigStub().config)
     if rank == 0 and world == 1 and not args.no_e2e and args.sample_size == 64:
         res["config"]["end_to_end"] = end_to_end(model, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

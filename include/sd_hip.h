@@ -38,7 +38,20 @@ typedef struct sd_unet_config {
     int norm_num_groups;         /* 32 */
     float norm_eps;              /* 1e-5 */
     int context_len;             /* 77 */
+    /* Weight / operand type of the MFMA contractions (BASELINE configs[4]: "fp8 MFMA weights"):
+     *   SD_DTYPE_BF16     - bf16 operands everywhere (v_mfma_f32_16x16x32_bf16);
+     *   SD_DTYPE_FP8_E4M3 - OCP e4m3 weights with one fp32 scale per output channel, and e4m3 activations with a
+     *                       static per-tensor scale written by the producing GroupNorm / LayerNorm / GEGLU epilogue,
+     *                       for the 3x3 resnet convs, proj_in, the self-attention QKV projection and both
+     *                       feed-forward GEMMs (v_mfma_f32_16x16x128_f8f6f4, fp32 accumulate, dequantised in the
+     *                       epilogue).  Attention, the prompt cross-attention, to_out / proj_out / shortcut GEMMs,
+     *                       the down/upsampler convs and conv_in / conv_out stay bf16.
+     * fp8_act_scale_*: activation scales x_fp8 = sat(x * scale) (0 = the defaults 8 and 2). */
+    int weight_dtype;
+    float fp8_act_scale_norm;    /* GroupNorm(+SiLU) / LayerNorm outputs */
+    float fp8_act_scale_ff;      /* GEGLU outputs (input of ff.net.2) */
 } sd_unet_config;
+enum { SD_DTYPE_BF16 = 0, SD_DTYPE_FP8_E4M3 = 1 };
 
 const char* sd_last_error(void);
 int sd_abi_version(void);
@@ -114,12 +127,14 @@ int sd_clip_encode(sd_clip* c, void* stream, const int* input_ids, int batch, fl
 
 /* Measurement hook for bench.py: the same forward with a hipEvent pair around every launch.  Per
  * op kind (0 sinusoid, 1 gemv, 2 conv_in, 3 groupnorm, 4 conv3x3, 5 gemm, 6 layernorm,
- * 7 attention, 8 conv_out) it returns summed milliseconds, launch count, algorithmic FLOPs and
- * algorithmic HBM bytes.  Synchronises the stream; never used inside a timed region. */
+ * 7 attention, 8 conv_out; 16 conv3x3 with fp8 operands, 17 gemm with fp8 operands) it returns summed
+ * milliseconds, launch count, algorithmic FLOPs and algorithmic HBM bytes in arrays of SD_PROFILE_KINDS = 32
+ * entries.  Synchronises the stream; never used inside a timed region. */
+#define SD_PROFILE_KINDS 32
 int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
                              float timestep, float* eps_out, void* workspace, long long workspace_bytes, int cache_mode,
-                             int cache_branch_id, double kind_ms[16], long long kind_launches[16],
-                             double kind_flops[16], double kind_bytes[16]);
+                             int cache_branch_id, double kind_ms[SD_PROFILE_KINDS], long long kind_launches[SD_PROFILE_KINDS],
+                             double kind_flops[SD_PROFILE_KINDS], double kind_bytes[SD_PROFILE_KINDS]);
 
 /* Debug/parity hook: copy a named intermediate (bf16 NHWC) of the LAST full forward into `out`
  * as fp32; names: "conv_in", "down0".."down3", "mid", "up0".."up3".  Synchronises the stream. */
@@ -166,6 +181,26 @@ int sd_op_conv_out(void* stream, const void* x, const void* Wp, const float* bia
                    int Cin, int Cout);
 int sd_op_time_embedding(void* stream, float t, const void* W1, const float* b1, const void* W2, const float* b2,
                          float* scratch, float* temb, int dim_in, int dim);
+
+/* ---- fp8-e4m3 operand path (SD_DTYPE_FP8_E4M3), operator level ------------------------------------------------
+ * X, W hold OCP e4m3 bytes; K / Cin count fp8 elements and are multiples of 128 (zero padded); wscale [N] fp32 is the
+ * per-output-channel weight scale, xscale the static activation scale: C = (X_fp8 . W_fp8^T) * wscale[n] / xscale
+ * + bias + bias2 + R.  epi = 1: GEGLU on interleaved W; with out_fp8 the result is stored as e4m3 bytes of
+ * sat(out * oscale) (ldc in bytes) -- the input of the next fp8 GEMM. */
+int sd_op_gemm_fp8(void* stream, const void* X, long long ldx, const void* W, const float* wscale, float xscale,
+                   const float* bias, const void* R, long long ldr, void* C, long long ldc, int M, int N, int K, int epi,
+                   int out_fp8, float oscale);
+/* W is e4m3 [Cout][Cin/128][3*3][128] */
+int sd_op_conv3x3_fp8(void* stream, const void* X, const void* W, const float* wscale, float xscale, const float* bias,
+                      const float* bias2, const void* R, void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride,
+                      int upsample);
+/* producers: GroupNorm(+SiLU) / LayerNorm writing e4m3 rows of Cpad = roundup(C, 128) bytes (pad zero), and a plain
+ * bf16 -> e4m3 conversion */
+int sd_op_groupnorm_fp8(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                        const float* beta, void* y, int B, int HW, int groups, float eps, int silu, int Cpad, float oscale);
+int sd_op_layernorm_fp8(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows, int C,
+                        int Cpad, float eps, float oscale);
+int sd_op_quantize_fp8(void* stream, const void* x_bf16, void* y_fp8, long long rows, int C, int Cpad, float scale);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,60 @@
+"""fp8-e4m3 emulation for the CPU oracle: the rounding points of the product's ``SD_DTYPE_FP8_E4M3`` plan
+(include/sd_hip.h::sd_unet_config.weight_dtype; BASELINE configs[4] "fp8 MFMA weights"), applied to the fp32
+restatement so that the HIP path can be compared against the reference arithmetic ON THE SAME ROUNDED OPERANDS.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- parity unpinned; the reference itself has no fp8 path
+(``configs/consistency_model_config.yaml:1-34``, ``src/experiments/consistency_model.py:9-52`` run fp16): what is
+emulated here is this build's own quantisation scheme, so that its error is separated from kernel error.
+
+Scheme (identical in csrc/unet.hip):
+  * weights of the resnet 3x3 convs, proj_in, attn1 to_q/to_k/to_v, ff.net.0.proj and ff.net.2: OCP e4m3fn, one
+    fp32 scale per OUTPUT channel (row): scale = amax / 448, w_q = rne(w / scale), saturating;
+  * the activations entering those contractions -- GroupNorm(+SiLU) and LayerNorm outputs (scale ``s_norm``) and the
+    GEGLU product (scale ``s_ff``) -- e4m3 of ``clamp(x * s, +-448)`` with a static per-tensor scale;
+  * everything else (attention, cross-attention, to_out, proj_out, shortcuts, down/upsampler convs, conv_in/out)
+    is not quantised.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+E4M3_MAX = 448.0
+
+
+def e4m3_round(x: torch.Tensor) -> torch.Tensor:
+    """Nearest-even rounding to the OCP e4m3fn grid with saturation at +-448 (fp32 in, fp32 out)."""
+    return x.float().clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def quantize_rows(w: torch.Tensor):
+    """Per-output-channel (dim 0) scale and e4m3 codes: w ~= q * scale[:, None...]."""
+    flat = w.float().reshape(w.shape[0], -1)
+    amax = flat.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / E4M3_MAX, torch.ones_like(amax))
+    q = e4m3_round(flat * (1.0 / scale)[:, None])     # the host packer multiplies by the reciprocal, as here
+    return q.reshape(w.shape), scale
+
+
+QUANTISED_SUFFIXES = (".conv1.weight", ".conv2.weight", ".proj_in.weight", ".attn1.to_q.weight", ".attn1.to_k.weight",
+                      ".attn1.to_v.weight", ".ff.net.0.proj.weight", ".ff.net.2.weight")
+
+
+class Fp8Emulation:
+    def __init__(self, weights: Dict[str, torch.Tensor], s_norm: float = 8.0, s_ff: float = 2.0):
+        self.s_norm, self.s_ff = float(s_norm), float(s_ff)
+        self.wq: Dict[str, torch.Tensor] = {}
+        for name, w in weights.items():
+            if name.endswith(QUANTISED_SUFFIXES) and ("resnets." in name or "attentions." in name):
+                q, scale = quantize_rows(w)
+                self.wq[name] = q * scale.reshape((-1,) + (1,) * (w.dim() - 1))
+
+    def w(self, weights, name):
+        return self.wq.get(name, weights[name])
+
+    def act_norm(self, x):
+        return e4m3_round(x * self.s_norm) / self.s_norm
+
+    def act_ff(self, x):
+        return e4m3_round(x * self.s_ff) / self.s_ff

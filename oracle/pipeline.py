@@ -25,7 +25,7 @@ def sample_loop(weights, cfg: UNetConfig, scheduler, prompt_embeds: torch.Tensor
                 deepcache: Optional[DeepCacheState] = None,
                 lcm_noise: Optional[torch.Tensor] = None,
                 max_steps: Optional[int] = None,
-                forced_eps: Optional[List[torch.Tensor]] = None):
+                forced_eps: Optional[List[torch.Tensor]] = None, fq=None):
     """Returns (final_latents, execution_time_s, x0_preds, trajectory).
 
     ``lcm_noise`` [N-1,B,4,H,W]: pre-drawn re-noising tensors for LCM so the
@@ -52,7 +52,7 @@ def sample_loop(weights, cfg: UNetConfig, scheduler, prompt_embeds: torch.Tensor
         if deepcache is not None:
             # DeepCache's wrapped unet.forward: index of t in scheduler.timesteps (A.5)
             deepcache.cur_timestep = list(int(x) for x in timesteps).index(int(t))
-        noise_pred = unet_forward(weights, cfg, latent_in, t, ctx, dc=deepcache)
+        noise_pred = unet_forward(weights, cfg, latent_in, t, ctx, dc=deepcache, fq=fq)
         if do_cfg:
             u, c = noise_pred.chunk(2)
             noise_pred = u + guidance_scale * (c - u)

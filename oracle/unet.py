@@ -100,28 +100,34 @@ def timestep_embedding(t: torch.Tensor, dim: int = 320) -> torch.Tensor:
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
 
-def resnet_block(w, p: str, x: torch.Tensor, temb: torch.Tensor, cfg: UNetConfig) -> torch.Tensor:
-    """ResnetBlock2D (A.3)."""
+def resnet_block(w, p: str, x: torch.Tensor, temb: torch.Tensor, cfg: UNetConfig, fq=None) -> torch.Tensor:
+    """ResnetBlock2D (A.3).  ``fq`` (oracle/fp8.py::Fp8Emulation) applies the build's fp8 rounding points."""
     g = cfg.norm_num_groups
+    W = (lambda n: fq.w(w, n)) if fq is not None else (lambda n: w[n])
     h = F.group_norm(x, g, w[p + "norm1.weight"], w[p + "norm1.bias"], cfg.norm_eps)
     h = F.silu(h)
-    h = F.conv2d(h, w[p + "conv1.weight"], w[p + "conv1.bias"], padding=1)
+    if fq is not None:
+        h = fq.act_norm(h)
+    h = F.conv2d(h, W(p + "conv1.weight"), w[p + "conv1.bias"], padding=1)
     tp = F.linear(F.silu(temb), w[p + "time_emb_proj.weight"], w[p + "time_emb_proj.bias"])
     h = h + tp[:, :, None, None]
     h = F.group_norm(h, g, w[p + "norm2.weight"], w[p + "norm2.bias"], cfg.norm_eps)
     h = F.silu(h)
-    h = F.conv2d(h, w[p + "conv2.weight"], w[p + "conv2.bias"], padding=1)
+    if fq is not None:
+        h = fq.act_norm(h)
+    h = F.conv2d(h, W(p + "conv2.weight"), w[p + "conv2.bias"], padding=1)
     if (p + "conv_shortcut.weight") in w:
         x = F.conv2d(x, w[p + "conv_shortcut.weight"], w[p + "conv_shortcut.bias"])
     return x + h
 
 
-def _attention(w, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int) -> torch.Tensor:
+def _attention(w, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int, fq=None) -> torch.Tensor:
     """diffusers Attention + AttnProcessor2_0: q/k/v no bias, to_out.0 with bias, SDPA."""
     b, n, c = x.shape
-    q = F.linear(x, w[p + "to_q.weight"])
-    k = F.linear(ctx, w[p + "to_k.weight"])
-    v = F.linear(ctx, w[p + "to_v.weight"])
+    W = (lambda nm: fq.w(w, nm)) if fq is not None else (lambda nm: w[nm])
+    q = F.linear(x, W(p + "to_q.weight"))
+    k = F.linear(ctx, W(p + "to_k.weight"))
+    v = F.linear(ctx, W(p + "to_v.weight"))
     d = c // heads
     q = q.view(b, n, heads, d).transpose(1, 2)
     k = k.view(b, -1, heads, d).transpose(1, 2)
@@ -131,22 +137,27 @@ def _attention(w, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int) -> tor
     return F.linear(o, w[p + "to_out.0.weight"], w[p + "to_out.0.bias"])
 
 
-def transformer_block(w, p: str, x: torch.Tensor, ctx: torch.Tensor, cfg: UNetConfig) -> torch.Tensor:
+def transformer_block(w, p: str, x: torch.Tensor, ctx: torch.Tensor, cfg: UNetConfig, fq=None) -> torch.Tensor:
     """Transformer2DModel with one BasicTransformerBlock (A.4), use_linear_projection=False."""
     b, c, hh, ww = x.shape
     res = x
+    W = (lambda n: fq.w(w, n)) if fq is not None else (lambda n: w[n])
+    A = fq.act_norm if fq is not None else (lambda v: v)
     h = F.group_norm(x, cfg.norm_num_groups, w[p + "norm.weight"], w[p + "norm.bias"], 1e-6)
-    h = F.conv2d(h, w[p + "proj_in.weight"], w[p + "proj_in.bias"])
+    h = F.conv2d(A(h), W(p + "proj_in.weight"), w[p + "proj_in.bias"])
     h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
     t = p + "transformer_blocks.0."
-    n1 = F.layer_norm(h, (c,), w[t + "norm1.weight"], w[t + "norm1.bias"], 1e-5)
-    h = h + _attention(w, t + "attn1.", n1, n1, cfg.num_heads)
+    n1 = A(F.layer_norm(h, (c,), w[t + "norm1.weight"], w[t + "norm1.bias"], 1e-5))
+    h = h + _attention(w, t + "attn1.", n1, n1, cfg.num_heads, fq)
     n2 = F.layer_norm(h, (c,), w[t + "norm2.weight"], w[t + "norm2.bias"], 1e-5)
-    h = h + _attention(w, t + "attn2.", n2, ctx, cfg.num_heads)
-    n3 = F.layer_norm(h, (c,), w[t + "norm3.weight"], w[t + "norm3.bias"], 1e-5)
-    proj = F.linear(n3, w[t + "ff.net.0.proj.weight"], w[t + "ff.net.0.proj.bias"])
+    h = h + _attention(w, t + "attn2.", n2, ctx, cfg.num_heads)          # the prompt cross-attention stays bf16
+    n3 = A(F.layer_norm(h, (c,), w[t + "norm3.weight"], w[t + "norm3.bias"], 1e-5))
+    proj = F.linear(n3, W(t + "ff.net.0.proj.weight"), w[t + "ff.net.0.proj.bias"])
     a, gate = proj.chunk(2, dim=-1)
-    ff = F.linear(a * F.gelu(gate), w[t + "ff.net.2.weight"], w[t + "ff.net.2.bias"])
+    hid = a * F.gelu(gate)
+    if fq is not None:
+        hid = fq.act_ff(hid)
+    ff = F.linear(hid, W(t + "ff.net.2.weight"), w[t + "ff.net.2.bias"])
     h = h + ff
     h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
     h = F.conv2d(h, w[p + "proj_out.weight"], w[p + "proj_out.bias"])
@@ -158,11 +169,11 @@ def transformer_block(w, p: str, x: torch.Tensor, ctx: torch.Tensor, cfg: UNetCo
 # --------------------------------------------------------------------------------------
 def unet_forward(w: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tensor, t,
                  ctx: torch.Tensor, dc: Optional[DeepCacheState] = None,
-                 taps: Optional[dict] = None) -> torch.Tensor:
+                 taps: Optional[dict] = None, fq=None) -> torch.Tensor:
     """eps = UNet(sample [N,4,H,W], t scalar, ctx [N,L,768]) -> [N,4,H,W].
 
     ``taps`` (optional dict) receives named intermediate activations for layer-by-layer
-    parity debugging.
+    parity debugging.  ``fq`` (oracle/fp8.py::Fp8Emulation) applies the rounding points of the build's fp8 plan.
     """
     n = sample.shape[0]
     nlev = len(cfg.block_out_channels)
@@ -187,11 +198,11 @@ def unet_forward(w: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tens
             for j in range(cfg.layers_per_block):
                 p = f"down_blocks.{i}.resnets.{j}."
                 hcur = _cached(dc, ("down", "resnet", i, j), i, j, "down",
-                               lambda hcur=hcur, p=p: resnet_block(w, p, hcur, temb, cfg))
+                               lambda hcur=hcur, p=p: resnet_block(w, p, hcur, temb, cfg, fq))
                 if cfg.attn_levels[i]:
                     p = f"down_blocks.{i}.attentions.{j}."
                     hcur = _cached(dc, ("down", "attentions", i, j), i, j, "down",
-                                   lambda hcur=hcur, p=p: transformer_block(w, p, hcur, ctx, cfg))
+                                   lambda hcur=hcur, p=p: transformer_block(w, p, hcur, ctx, cfg, fq))
                 outs.append(hcur)
             if i < nlev - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv."
@@ -208,9 +219,9 @@ def unet_forward(w: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tens
 
     # ---- mid ----
     def run_mid(h_in=h):
-        hcur = resnet_block(w, "mid_block.resnets.0.", h_in, temb, cfg)
-        hcur = transformer_block(w, "mid_block.attentions.0.", hcur, ctx, cfg)
-        hcur = resnet_block(w, "mid_block.resnets.1.", hcur, temb, cfg)
+        hcur = resnet_block(w, "mid_block.resnets.0.", h_in, temb, cfg, fq)
+        hcur = transformer_block(w, "mid_block.attentions.0.", hcur, ctx, cfg, fq)
+        hcur = resnet_block(w, "mid_block.resnets.1.", hcur, temb, cfg, fq)
         return hcur
     h = _cached(dc, ("mid", "mid_block", 0, 0), 0, 0, "mid", run_mid)
     if taps is not None:
@@ -235,11 +246,11 @@ def unet_forward(w: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tens
                 p = f"up_blocks.{i}.resnets.{j}."
                 hcur = _cached(dc, ("up", "resnet", rb, rl), rb, rl, "up",
                                lambda hcur=hcur, skip=skip, p=p: resnet_block(
-                                   w, p, torch.cat([hcur, skip], dim=1), temb, cfg))
+                                   w, p, torch.cat([hcur, skip], dim=1), temb, cfg, fq))
                 if has_attn:
                     p = f"up_blocks.{i}.attentions.{j}."
                     hcur = _cached(dc, ("up", "attentions", rb, rl), rb, rl, "up",
-                                   lambda hcur=hcur, p=p: transformer_block(w, p, hcur, ctx, cfg))
+                                   lambda hcur=hcur, p=p: transformer_block(w, p, hcur, ctx, cfg, fq))
             if i < nlev - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv."
                 hcur = _cached(dc, ("up", "upsampler", rb, 0), rb, 0, "up",

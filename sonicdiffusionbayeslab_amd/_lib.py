@@ -23,7 +23,12 @@ class SdUnetConfig(C.Structure):
         ("num_levels", C.c_int), ("block_out_channels", C.c_int * 8), ("layers_per_block", C.c_int),
         ("attn_levels", C.c_int * 8), ("cross_attention_dim", C.c_int), ("num_heads", C.c_int),
         ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("context_len", C.c_int),
+        ("weight_dtype", C.c_int), ("fp8_act_scale_norm", C.c_float), ("fp8_act_scale_ff", C.c_float),
     ]
+
+
+DTYPE_BF16, DTYPE_FP8_E4M3 = 0, 1
+DTYPES = {"bf16": DTYPE_BF16, "fp8": DTYPE_FP8_E4M3, "fp8_e4m3": DTYPE_FP8_E4M3}
 
 
 class SdClipConfig(C.Structure):
@@ -74,6 +79,11 @@ _SIGS = {
     "sd_op_conv_in": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "sd_op_conv_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "sd_op_time_embedding": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
+    "sd_op_gemm_fp8": (_i, [_vp, _vp, _ll, _vp, _vp, _f, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f]),
+    "sd_op_conv3x3_fp8": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "sd_op_groupnorm_fp8": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _f]),
+    "sd_op_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f]),
+    "sd_op_quantize_fp8": (_i, [_vp, _vp, _vp, _ll, _i, _i, _f]),
 }
 
 

@@ -15,6 +15,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
+typedef __attribute__((ext_vector_type(8))) int i32x8;       // one fp8 MFMA A/B fragment: 32 K bytes (8 VGPRs)
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+// two 16-byte halves -> one 32-byte fragment (a register-sequence, no copies when the halves are loaded in place)
+__device__ __forceinline__ i32x8 cat_u32x4(u32x4 lo, u32x4 hi) {
+    const u32x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(i32x8, r);
+}
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
@@ -30,6 +38,15 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     f32x2_t v = {lo, hi};
     bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
     return __builtin_bit_cast(unsigned, r);
+}
+
+// four f32 -> four OCP e4m3 bytes (byte 0 = a), saturating at +-448 (the conversion alone gives NaN above the
+// finite range)
+__device__ __forceinline__ unsigned pack4fp8(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    const int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
 }
 
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16

@@ -18,6 +18,11 @@
 //   K order = (slice, tap, channel), weights packed [Cout][Cin/64][9][64] as for the implicit GEMM.
 //   Zero padding and M/N tails read the zero page.
 //   Split-K runs over channel slices (fp32 slabs + splitk_reduce_kernel of gemm_conv.hip).
+//   DT = 1: fp8-e4m3 operands.  A 128-byte pixel slot / W row then holds 128 channels (a "slice" is 128 channels,
+//   Cin padded to a multiple of 128 by the producer), the byte geometry of halo, W stages and DMA pieces is unchanged,
+//   and one v_mfma_f32_16x16x128_f8f6f4 replaces the two bf16 k-steps of a tap: twice the flops per staged byte and
+//   per matrix-core cycle.  Chunk swizzle f(slot) = bit1(slot) | (slot & 4) (conflict-free for the two 16-byte reads
+//   of a lane's 32 K bytes at every tap shift); the epilogue dequantises with wscale[n] / xscale.
 #include "common.h"
 #include "kernels.h"
 
@@ -43,7 +48,11 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+__device__ __forceinline__ int swz_of(int row, int dt) { return dt ? (((row >> 1) & 1) | (row & 4)) : (row & 7); }
+
+template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
+    constexpr int ESZ = DT ? 1 : 2;               // bytes per operand element; a slice = 128 / ESZ channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nwork = ntiles * p.splitk;
     if (work >= nwork) return;
-    const int S = p.Cin >> 6;
+    const int S = (p.Cin * ESZ) >> 7;
 
     // tile geometry: BM / PIX pieces of RW whole OUTPUT rows (more than one piece only when an image has
     // fewer than 256 pixels).  With the fused nearest-2x upsample (p.up = 1) the halo lives in the
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
         const int i = slot / PP, rem = slot - i * PP;
         const int hy = rem / PW, hx = rem - hy * PW;
         const bool ok = slot < HP && hx >= 1 && hx <= p.Win;
-        hrel[j] = ok ? ((((hy - 1) * p.Win + (hx - 1)) * p.Cin * 2 + ((cpos ^ (slot & 7)) << 4)) | i |
+        hrel[j] = ok ? ((((hy - 1) * p.Win + (hx - 1)) * p.Cin * ESZ + ((cpos ^ swz_of(slot, DT)) << 4)) | i |
                         (hy == 0 ? 4 : 0) | (hy == RWin + 1 ? 8 : 0))
                      : HREL_ZERO;
     }
@@ -125,15 +134,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             const int ybase = (mp & (HWo - 1)) >> (lgW + up);          // its first input row
             const bool ok = hrel[j] != HREL_ZERO && mp < p.M && !((hrel[j] & 4) && ybase == 0) &&
                             !((hrel[j] & 8) && ybase + RWin == p.Hin);
-            const unsigned base = (unsigned)(((long)b * p.Hin + ybase) * p.Win * p.Cin * 2);
+            const unsigned base = (unsigned)(((long)b * p.Hin + ybase) * p.Win * p.Cin * ESZ);
             hoff[j] = ok ? base + (unsigned)(hrel[j] & ~15) : NOSRC;
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pc = wpiece(i);
             const int n = n0 + pc * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (lane >> 3);
-            woffs[i] = n < p.N ? (unsigned)((long)n * p.ldw * 2 + (c << 4)) : NOSRC;
+            const int c = (lane & 7) ^ swz_of(lane >> 3, DT);
+            woffs[i] = n < p.N ? (unsigned)((long)n * p.ldw * ESZ + (c << 4)) : NOSRC;
         }
     };
     auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch (zero page), keeps the loop branch-free
@@ -161,7 +170,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
         hbase[f] = i * PP + PW + 1;
     }
     const int wfrag = (wn * WTN + lrow) * 128;
-    const int wswz0 = (lq ^ (lane & 7)) << 4;     // k-step 1 = ^ 64
+    // bf16: k-step 0 reads chunk lq ^ (row & 7), k-step 1 = ^ 64; fp8: chunks 2 lq and 2 lq + 1 (= ^ 16), each ^ f(row)
+    const int wswz0 = DT ? ((2 * lq) ^ swz_of(lane, 1)) << 4 : (lq ^ (lane & 7)) << 4;
 
     f32x4 acc[TN][TM];
     bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
@@ -171,6 +181,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
 #pragma unroll
             for (int b = 0; b < TM; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    };
+    // fp8: all W fragments of the tap (TN x 32 B) + a two-deep ring of X fragments; the MFMAs walk the pixel tiles
+    i32x8 wq[DT ? TN : 1], xq[2];
+    auto ld32 = [&](const char* base, int off) -> i32x8 {
+        return cat_u32x4(*(const u32x4*)(base + off), *(const u32x4*)(base + (off ^ 16)));
     };
 
     char* const Hb0 = smem;
@@ -199,6 +214,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             const char* hcur = hsel ? Hb1 : Hb0;
             char* hnext = hsel ? Hb0 : Hb1;
             const bool more = s + 1 < s_end;
+            // The 36 fragment addresses (9 taps x 4 pixel tiles) do not depend on the slice; hoisted out of this loop
+            // they cost 36 VGPRs and push the DMA descriptors into scratch, whose reloads drain the counted vmcnt
+            // pipeline.  Recomputing them per tap is ~6 VALU per address under 640-1280 cycles of MFMA.
+#pragma unroll
+            for (int f = 0; f < TM; ++f) asm volatile("" : "+v"(hbase[f]), "+v"(hrc[f]));
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 // In-order vmcnt: tile kt's W stage (issued two K tiles ago) and, at tap 0, the slice's halo have
@@ -223,21 +243,39 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 for (int f = 0; f < TM; ++f) {
                     const int hp = hbase[f] + (((hrc[f] >> 16) + (tap / 3 - 1)) >> up) * PW +
                                    (((hrc[f] & 0xffff) + (tap % 3 - 1)) >> up);
-                    xa[f] = hp * 128 + ((lq ^ (hp & 7)) << 4);
-                    xf0[f] = *(const bf16x8*)(hcur + xa[f]);
+                    xa[f] = hp * 128 + (DT ? (((2 * lq) ^ swz_of(hp, 1)) << 4) : ((lq ^ (hp & 7)) << 4));
                 }
+                if (DT) {
 #pragma unroll
-                for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
-                issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int a = 0; a < TN; ++a) wq[a] = ld32(wcur, wfrag + a * 2048 + wswz0);
+                    xq[0] = ld32(hcur, xa[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
+                    issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
+                    for (int b = 0; b < TM; ++b) {
+                        if (b + 1 < TM) xq[(b + 1) & 1] = ld32(hcur, xa[b + 1]);
 #pragma unroll
-                for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
-                mfmas(xf0, wf0);
-                mfmas(xf1, wf1);
+                        for (int a = 0; a < TN; ++a)
+                            acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq[a], xq[b & 1], acc[a][b], 0, 0, 0, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < TM; ++f) xf0[f] = *(const bf16x8*)(hcur + xa[f]);
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
+                    issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
+                    mfmas(xf0, wf0);
+                    mfmas(xf1, wf1);
+                }
                 wst = wst == 2 ? 0 : wst + 1;
             }
             hsel ^= 1;
@@ -247,6 +285,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
         // no ordinary load is outstanding once the next item's LDS-DMA is in flight ----------------------
         // (accumulator layout as gemm_kernel: a lane owns 4 consecutive channels of one pixel per 16x16 tile)
         const int em0 = m0, en0 = n0, esplit = split;
+        if (DT && p.splitk == 1) {     // dequantise: per-output-channel weight scale / per-tensor activation scale
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+                const f32x4 sv = *(const f32x4*)(p.wscale + n) * p.xscale_inv;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] *= sv;
+            }
+        }
         if (p.splitk == 1) {
             if (p.R) {
                 u32x2 rr[TN][TM];
@@ -370,14 +417,15 @@ bool sd_conv_halo_applicable(const GemmArgs& a) {
     if ((W & (W - 1)) || ((H * W) & (H * W - 1))) return false;   // the kernel decodes pixels with shifts
     if ((BM / PIX) * ((RW >> a.up) + 2) * (a.Win + 2) > HSLOTS) return false;
     if ((long)a.M * a.Cin * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
+    if (a.dt == 1 && a.Cin % 128) return false;
     return true;
 }
 
 // Split-K over channel slices: one 8-wave workgroup per CU, so aim at >= 256 work items.
-int sd_conv_halo_splitk(int M, int N, int Cin) {
+int sd_conv_halo_splitk(int M, int N, int Cin, int dt) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (tiles >= 192) return 1;
-    const int S = Cin / 64;
+    const int S = Cin / (dt ? 128 : 64);
     int want = (256 + tiles - 1) / tiles;
     int maxs = tiles < 64 ? S / 2 : S / 4;       // >= 4 slices (36 K tiles) per split; >= 2 on tiny grids
     int s = want < maxs ? want : maxs;
@@ -386,12 +434,12 @@ int sd_conv_halo_splitk(int M, int N, int Cin) {
 }
 
 // Split factor for a 3x3 conv, whichever kernel will run it (the plan sizes the slab with this).
-int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up) {
+int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up, int dt) {
     static const char* env = getenv("SD_SPLITK");
     GemmArgs a;
-    a.M = M; a.N = N; a.Cin = Cin; a.K = 9 * Cin; a.ldw = a.K; a.Hin = Hin; a.Win = Win; a.stride = stride; a.up = up;
-    if (!env && sd_conv_halo_applicable(a)) return sd_conv_halo_splitk(M, N, Cin);
-    return sd_gemm_splitk(M, N, 9 * Cin);
+    a.M = M; a.N = N; a.Cin = Cin; a.K = 9 * Cin; a.ldw = a.K; a.Hin = Hin; a.Win = Win; a.stride = stride; a.up = up; a.dt = dt;
+    if (!env && sd_conv_halo_applicable(a)) return sd_conv_halo_splitk(M, N, Cin, dt);
+    return sd_gemm_splitk(M, N, dt ? 9 * Cin / 2 : 9 * Cin);      // the heuristic counts 128-byte K tiles
 }
 
 int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
@@ -400,17 +448,20 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     a.tiles_n = (a.N + BN - 1) / BN;
     if (a.ldw == 0) a.ldw = a.K;
     if (a.slab == nullptr || a.splitk < 1) a.splitk = 1;
-    SD_REQUIRE(a.splitk <= a.Cin / 64, "conv3x3 halo: splitk %d exceeds the %d channel slices", a.splitk, a.Cin / 64);
+    const int slices = a.Cin / (a.dt ? 128 : 64);
+    SD_REQUIRE(a.splitk <= slices, "conv3x3 halo: splitk %d exceeds the %d channel slices", a.splitk, slices);
     static bool attr_set = false;
     if (!attr_set) {
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
     a.tune = tune;
     int grid = a.tiles_m * a.tiles_n * a.splitk;
     if (grid > 256) grid = 256;                  // persistent: one 8-wave workgroup per CU
-    hipLaunchKernelGGL(conv_halo_kernel, dim3(grid), dim3(512), SMEM, stream, a);
+    if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
     if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
     return 0;

@@ -13,6 +13,14 @@
 // * Out-of-range rows (M/N tails, conv zero padding) read a zero page instead of branching.
 // * MFMA v_mfma_f32_16x16x32_bf16 with W as the A operand: a lane then owns 4 consecutive
 //   output columns of one row, i.e. one 8-byte packed bf16 store per 16x16 tile.
+// * DT = 1: fp8-e4m3 (OCP) operands -- X quantised by its producer (GroupNorm / LayerNorm / GEGLU epilogue,
+//   static per-tensor scale), W quantised per output channel on the host.  The same 128-byte LDS rows then hold
+//   128 K elements and one v_mfma_f32_16x16x128_f8f6f4 (32 cycles) replaces two bf16 MFMAs (2 x 16 cycles) per
+//   16x16 tile and K tile: twice the flops per LDS-fill byte, fragment-read byte and matrix-core cycle.  A lane
+//   reads its 32 K bytes of a row as two ds_read_b128; the chunk swizzle is f(row) = bit1(row) | (row & 4)
+//   (conflict-free for this read pattern, tools/lds_swizzle_search.py).  A and B fragments are read with the
+//   same (lane group, byte) -> k map, so the contraction does not depend on the instruction's internal k order.
+//   The epilogue multiplies by wscale[n] / xscale before bias / residual.
 #include "common.h"
 #include "kernels.h"
 
@@ -36,9 +44,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // STAGES = 2: classic double buffer (wait for everything, one barrier per K tile).
 // STAGES = 3: two K tiles in flight; the wait before the barrier is a COUNTED vmcnt that leaves the
 //             newest tile's LDS-DMA outstanding, so HBM/L2 latency spans a whole tile of MFMA work.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI, int DT>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int ESZ = DT ? 1 : 2;               // bytes per operand element
+    constexpr int KTE = 128 / ESZ;                // K elements per 128-byte LDS row = per K tile
+    static_assert(!DT || STAGES == 2, "fp8 path: 2-stage loop only");
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int XI = BM / 8, WI = BN / 8;  // 1-KiB glds wave-instructions per tile
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     }
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nwork = ntiles * p.splitk;
-    const int KTall = p.K / 64;
+    const int KTall = p.K / KTE;
     int split = 0, m0 = 0, n0 = 0, kt_begin = 0, KT = 0;
     auto decode = [&](int w) {
         split = w / ntiles;
@@ -83,18 +94,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
 
     // ---- per-lane source descriptors -------------------------------------------------
     const int lrow8 = lane >> 3;                 // row inside an 8-row glds piece
-    const int gch = (lane & 7) ^ lrow8;          // global 16-B chunk this lane fetches (swizzle)
+    // global 16-B chunk this lane fetches (swizzle): bf16 rows by (row & 7), fp8 rows by bit1(row) | (row & 4)
+    const int gch = (lane & 7) ^ (DT ? (((lrow8 >> 1) & 1) | (lrow8 & 4)) : lrow8);
     const char* zero = (const char*)p.zero_page;
 
     // Everything that does not change along K is folded into one pointer per row here, so the
     // per-tile work is a scalar offset add + a select (the K loop is otherwise address-VALU bound).
     //   GEMM: row pointers into X (and X2 for the second K segment); null = zero page.
     //   CONV: pointer of the tap (0,0) input pixel + a 9-bit validity mask of the taps.
-    const bf16_t* xptr[XPW];
-    const bf16_t* xptr2[XPW];
+    const char* xptr[XPW];        // byte pointers: element size is 2 (bf16) or 1 (fp8)
+    const char* xptr2[XPW];
     int xmask[XPW];
     int xoy[XPW], xox[XPW], xb[XPW];   // only the fused-upsample conv path recomputes pixels per tap
-    const bf16_t* wsrc[WPW];
+    const char* wsrc[WPW];
     const int Hv = p.Hin << p.up, Wv = p.Win << p.up;
     auto setup = [&]() {
 #pragma unroll
@@ -103,15 +115,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         const int m = m0 + inst * 8 + lrow8;
         xptr2[i] = nullptr; xmask[i] = 0; xoy[i] = xox[i] = xb[i] = 0;
         if (AMODE == AMODE_GEMM) {
-            xptr[i] = m < p.M ? p.X + (long)m * p.ldx + gch * 8 : nullptr;
-            if (p.X2) xptr2[i] = m < p.M ? p.X2 + (long)m * p.ldx2 + gch * 8 : nullptr;
+            xptr[i] = m < p.M ? (const char*)p.X + (long)m * p.ldx * ESZ + gch * 16 : nullptr;
+            if (p.X2) xptr2[i] = m < p.M ? (const char*)p.X2 + (long)m * p.ldx2 * ESZ + gch * 16 : nullptr;
         } else {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
             const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
             xoy[i] = y0; xox[i] = x0; xb[i] = m < p.M ? b * p.Hin * p.Win : -1;
-            xptr[i] = p.X + ((long)b * p.Hin * p.Win + (long)y0 * p.Win + x0) * p.Cin + gch * 8;
+            xptr[i] = (const char*)p.X + ((long)b * p.Hin * p.Win + (long)y0 * p.Win + x0) * p.Cin * ESZ + gch * 16;
             int mask = 0;
             if (m < p.M) {
 #pragma unroll
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         const int inst = wave + i * NW;
         const int n = n0 + inst * 8 + lrow8;
         const long wb = p.rows_per_batch > 0 ? (long)(m0 / p.rows_per_batch) * p.w_batch_stride : 0;
-        wsrc[i] = (inst < WI && n < p.N) ? p.W + wb + (long)n * p.ldw + gch * 8 : nullptr;
+        wsrc[i] = (inst < WI && n < p.N) ? (const char*)p.W + (wb + (long)n * p.ldw) * ESZ + gch * 16 : nullptr;
     }
     };
 
@@ -137,14 +149,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     auto stage = [&](int kt, int buf) {
         char* xs = smem + buf * STAGE_BYTES;
         char* ws = xs + BM * 128;
-        const int k0 = kt * 64;
+        const int k0 = kt * KTE;
         if (AMODE == AMODE_GEMM) {
             const bool seg2 = k0 >= p.K1;
-            const int kk = seg2 ? k0 - p.K1 : k0;
+            const int kk = (seg2 ? k0 - p.K1 : k0) * ESZ;
 #pragma unroll
             for (int i = 0; i < XPW; ++i) {
                 const int inst = wave + i * NW;
-                const bf16_t* rp = seg2 ? xptr2[i] : xptr[i];
+                const char* rp = seg2 ? xptr2[i] : xptr[i];
                 const void* src = rp ? (const void*)(rp + kk) : (const void*)zero;
                 glds16(src, xs + inst * 1024);
             }
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             const int cs = kt / 9, tap = kt - cs * 9;
             const int dy = tap / 3, dx = tap - dy * 3;
             if (!p.up) {
-                const long toff = ((long)dy * p.Win + dx) * p.Cin + cs * 64;   // wave-uniform
+                const long toff = (((long)dy * p.Win + dx) * p.Cin + cs * KTE) * ESZ;   // wave-uniform
 #pragma unroll
                 for (int i = 0; i < XPW; ++i) {
                     const int inst = wave + i * NW;
@@ -160,14 +172,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                     glds16(src, xs + inst * 1024);
                 }
             } else {
-                const int coff = cs * 64 + gch * 8;
+                const int coff = cs * 128 + gch * 16;
 #pragma unroll
                 for (int i = 0; i < XPW; ++i) {
                     const int inst = wave + i * NW;
                     const int ty = xoy[i] + dy, tx = xox[i] + dx;
                     const bool ok = (xmask[i] >> tap) & 1;
                     const int iy = ty >> 1, ix = tx >> 1;
-                    const void* src = ok ? (const void*)(p.X + ((long)(xb[i] + iy * p.Win + ix)) * p.Cin + coff)
+                    const void* src = ok ? (const void*)((const char*)p.X + ((long)(xb[i] + iy * p.Win + ix)) * p.Cin * ESZ + coff)
                                          : (const void*)zero;
                     glds16(src, xs + inst * 1024);
                 }
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         for (int i = 0; i < WPW; ++i) {
             const int inst = wave + i * NW;
             if (inst < WI) {     // wave-uniform
-                const void* src = wsrc[i] ? (const void*)(wsrc[i] + k0) : (const void*)zero;
+                const void* src = wsrc[i] ? (const void*)(wsrc[i] + k0 * ESZ) : (const void*)zero;
                 glds16(src, ws + inst * 1024);
             }
         }
@@ -188,15 +200,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
 
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int lrow = lane & 15, lq = lane >> 4;
-    const int swz[2] = {((lq) ^ (lane & 7)) << 4, ((4 + lq) ^ (lane & 7)) << 4};
+    // bf16: k-step ks reads chunk (4 ks + lq) ^ (row & 7); fp8: the lane's 32 K bytes are chunks 2 lq, 2 lq + 1, each ^ f(row)
+    const int f8sw = ((lane >> 1) & 1) | (lane & 4);
+    const int swz[2] = {DT ? ((2 * lq) ^ f8sw) << 4 : ((lq) ^ (lane & 7)) << 4,
+                        DT ? ((2 * lq + 1) ^ f8sw) << 4 : ((4 + lq) ^ (lane & 7)) << 4};
     const int xoff = (wm * WTM + lrow) * 128;
     const int woff = BM * 128 + (wn * WTN + lrow) * 128;
 
     // One K tile = two 32-deep k-steps.  The fragments of k-step 0 are read BEFORE the next tile's
     // LDS-DMA is issued (a glds costs the issuing wave ~60 cycles each, which hides the ds_read
     // latency), k-step 1's fragments are read under k-step 0's MFMAs.
-    constexpr bool FRAG_DB = TM * TN * 4 + (TM + TN) * 8 <= 200;   // accumulators + two fragment sets
-    bf16x8 xf0[TM], wf0[TN], xf1[FRAG_DB ? TM : 1], wf1[FRAG_DB ? TN : 1];
+    constexpr bool FRAG_DB = !DT && TM * TN * 4 + (TM + TN) * 8 <= 200;   // accumulators + two fragment sets
+    bf16x8 xf0[DT ? 1 : TM], wf0[DT ? 1 : TN], xf1[FRAG_DB ? TM : 1], wf1[FRAG_DB ? TN : 1];
+    // fp8: all W fragments of the tile (TN x 32 B) + a two-deep ring of X fragments, MFMAs walk the M tiles
+    i32x8 wq[DT ? TN : 1], xq[2];
+    auto ld32 = [&](const char* ptr) -> i32x8 {
+        return cat_u32x4(*(const u32x4*)(ptr + swz[0]), *(const u32x4*)(ptr + swz[1]));
+    };
     auto load_frags = [&](const char* sb, int ks, bf16x8* xf, bf16x8* wf) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
@@ -236,6 +256,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const char* sb = smem + ((g + kt) & 1) * STAGE_BYTES;
+            if (DT) {
+#pragma unroll
+                for (int t = 0; t < TN; ++t) wq[t] = ld32(sb + woff + t * 2048);
+                xq[0] = ld32(sb + xoff);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < KT) stage(kt_begin + kt + 1, (g + kt + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    if (b + 1 < TM) xq[(b + 1) & 1] = ld32(sb + xoff + (b + 1) * 2048);
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq[a], xq[b & 1], acc[a][b], 0, 0, 0, 0, 0, 0);
+                }
+                continue;
+            }
             load_frags(sb, 0, xf0, wf0);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < KT) stage(kt_begin + kt + 1, (g + kt + 1) & 1);
@@ -282,6 +318,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     // load is outstanding once the LDS-DMA prefetch is in flight (hipcc would drain everything with
     // vmcnt(0) at their first use) and phase B is stores only.
     const int em0 = m0, en0 = n0, esplit = split;
+    if (DT && p.splitk == 1) {     // dequantise: per-output-channel weight scale / per-tensor activation scale
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
+            const f32x4 sv = *(const f32x4*)(p.wscale + n) * p.xscale_inv;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] *= sv;
+        }
+    }
     if (p.splitk == 1) {
         if (EPI == EPI_STD && p.R) {
             // all residual loads of the tile issued back to back (rows clamped instead of branched, so
@@ -360,7 +405,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             primed = true;
             // phase B issues exactly EPI_STORES stores per wave iff the finished tile is full
             stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && (p.ldc & 7) == 0 && p.splitk == 1 &&
-                             !(p.tune & (32 | 64 | 8));
+                             !(p.tune & (32 | 64 | 8)) && !p.out_fp8;
         }
     }
 
@@ -418,7 +463,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     } else {
         // GEGLU: weight rows were packed so that every 32-column group is [16 value | 16 gate];
         // two output tiles (four accumulator tiles) are paired for 16-byte stores as above
-        const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64);
+        const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64) && !p.out_fp8;
+        if (p.out_fp8) {
+            // fp8 output (input of ff.net.2): a lane owns 4 consecutive bytes of a row per output tile, the four lane
+            // groups of a row 16 contiguous bytes
+#pragma unroll
+            for (int a = 0; a < TN; a += 2) {
+                const int n = en0 + wn * WTN + a * 16;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int m = em0 + wm * WTM + b * 16 + lrow;
+                    const f32x4 va = acc[a][b], vg = acc[a + 1][b];
+                    const f32x2_t lo = geglu_pair(f32x2_t{va[0], va[1]}, f32x2_t{vg[0], vg[1]}) * p.oscale;
+                    const f32x2_t hi = geglu_pair(f32x2_t{va[2], va[3]}, f32x2_t{vg[2], vg[3]}) * p.oscale;
+                    if (m < p.M) *(unsigned*)((char*)p.C + (long)m * p.ldc + (n >> 1) + lq * 4) = pack4fp8(lo[0], lo[1], hi[0], hi[1]);
+                }
+            }
+        } else {
         auto geglu_tile = [&](int a, int b) -> u32x2 {      // output tile of accumulator pair (a, a+1)
             const f32x4 va = acc[a][b], vg = acc[a + 1][b];
 #ifdef GEGLU_NOGELU
@@ -458,6 +520,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 if (a + 2 < TN) geglu_narrow(a + 2);
             }
         }
+        }
     }
     if (!more_work) break;
     if (STAGES != 2) __syncthreads();   // 3-stage path re-runs its prologue: all LDS reads must be done
@@ -473,6 +536,7 @@ __global__ void splitk_reduce_kernel(const GemmArgs p) {
     const long off = (long)m * p.N + n;
     f32x4 v = *(const f32x4*)(p.slab + off);
     for (int s = 1; s < p.splitk; ++s) v += *(const f32x4*)(p.slab + (long)s * p.M * p.N + off);
+    if (p.wscale) v *= *(const f32x4*)(p.wscale + n) * p.xscale_inv;      // fp8 operands: dequantise the raw sums
     if (p.bias) v += *(const f32x4*)(p.bias + n);
     if (p.bias2) v += *(const f32x4*)(p.bias2 + n);
     if (p.R) {
@@ -483,7 +547,7 @@ __global__ void splitk_reduce_kernel(const GemmArgs p) {
     *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int AMODE, int EPI, int DT = 0>
 int launch(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -494,7 +558,7 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     a.tune = tune;
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, AMODE, EPI>;
+    auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, AMODE, EPI, DT>;
     static bool attr_set = false;
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -543,7 +607,30 @@ int sd_gemm_splitk(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
+static int check_fp8(const GemmArgs& a, const char* what) {
+    SD_REQUIRE(a.wscale != nullptr && a.xscale_inv > 0.f, "%s fp8: weight scales / activation scale missing", what);
+    SD_REQUIRE(a.K % 128 == 0 && a.K >= 128, "%s fp8: K=%d must be a positive multiple of 128", what, a.K);
+    SD_REQUIRE(a.X2 == nullptr && a.K1 == a.K, "%s fp8: no second K segment", what);
+    SD_REQUIRE(a.rows_per_batch == 0, "%s fp8: per-sample weights are bf16 only", what);
+    SD_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "%s fp8: operands must be 16-byte aligned", what);
+    return 0;
+}
+
 int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
+    if (a.dt == 1) {
+        if (check_fp8(a, "gemm")) return -1;
+        SD_REQUIRE(a.N % 4 == 0 && a.M > 0 && a.N > 0 && a.zero_page, "gemm fp8: bad problem");
+        SD_REQUIRE(a.ldx % 16 == 0 && (a.ldw == 0 || a.ldw % 16 == 0), "gemm fp8: row strides must be multiples of 16 bytes");
+        if (epi == EPI_GEGLU) {
+            SD_REQUIRE(a.N % 32 == 0, "geglu gemm: N=%d must be a multiple of 32", a.N);
+            SD_REQUIRE(!a.out_fp8 || (a.ldc % 4 == 0), "geglu gemm fp8 out: ldc=%ld must be a multiple of 4 bytes", a.ldc);
+            if (a.N % 256 == 0) return launch<256, 256, 4, 2, 2, AMODE_GEMM, EPI_GEGLU, 1>(a, stream);
+            return launch<128, 128, 2, 2, 2, AMODE_GEMM, EPI_GEGLU, 1>(a, stream);
+        }
+        SD_REQUIRE(epi == EPI_STD && !a.out_fp8, "gemm fp8: epilogue %d not built", epi);
+        return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD, 1>(a, stream);
+    }
+    SD_REQUIRE(!a.out_fp8, "gemm: fp8 output needs fp8 operands");
     SD_REQUIRE(a.K % 64 == 0 && a.K >= 64, "gemm: K=%d must be a positive multiple of 64", a.K);
     SD_REQUIRE(a.N % 4 == 0, "gemm: N=%d must be a multiple of 4", a.N);
     SD_REQUIRE(a.K1 % 64 == 0 && a.K1 <= a.K, "gemm: K1=%d must be a multiple of 64 and <= K", a.K1);
@@ -572,6 +659,10 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
 }
 
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
+    if (a.dt == 1) {
+        if (check_fp8(a, "conv3x3")) return -1;
+        SD_REQUIRE(a.Cin % 128 == 0, "conv3x3 fp8: Cin=%d must be a multiple of 128 (pad the channels)", a.Cin);
+    }
     SD_REQUIRE(a.Cin % 64 == 0, "conv3x3: Cin=%d must be a multiple of 64", a.Cin);
     SD_REQUIRE(a.K == 9 * a.Cin, "conv3x3: K must be 9*Cin");
     SD_REQUIRE(a.N % 4 == 0, "conv3x3: Cout=%d must be a multiple of 4", a.N);
@@ -584,6 +675,7 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
                a.Hin, a.Win, a.stride, a.up);
     SD_REQUIRE(a.M % (a.Hout * a.Wout) == 0, "conv3x3: M not a multiple of Hout*Wout");
     if (sd_conv_halo_applicable(a)) return sd_launch_conv3x3_halo(a, stream);
+    if (a.dt == 1) return launch<128, 160, 2, 2, 2, AMODE_CONV, EPI_STD, 1>(a, stream);
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_CONV, EPI_STD>(a, stream);
     return launch<128, 160, 2, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
 }

@@ -32,6 +32,13 @@ struct GemmArgs {
     int sm_valid = 0;                 // EPI 2: softmax over the first sm_valid of every 80 output columns
     int tiles_m = 0, tiles_n = 0;     // filled by the launcher
     int tune = 0;                     // experiment knobs, filled by the launcher from SD_GEMM_TUNE
+    // fp8-e4m3 operands (dt = 1): X and W hold OCP e4m3 bytes, K (and ldx / ldw / Cin) count fp8 elements and are
+    // multiples of 128; the epilogue multiplies the fp32 sums by wscale[n] * xscale_inv before bias / residual.
+    int dt = 0;
+    const float* wscale = nullptr;    // [N] fp32: per-output-channel weight scale (W = W_fp8 * wscale[n])
+    float xscale_inv = 1.0f;          // 1 / activation scale (X_fp8 = sat(X * xscale))
+    int out_fp8 = 0;                  // GEGLU epilogue only: store e4m3 bytes (ldc in bytes) ...
+    float oscale = 1.0f;              // ... of out * oscale
 };
 
 int sd_gemm_splitk(int M, int N, int K);   // heuristic split factor (1 = none) for the std epilogue
@@ -40,7 +47,7 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
 void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // slab -> C (+bias +bias2 +R)
 // conv_halo.hip: LDS-resident-halo kernel for stride-1 convs on whole-row tiles
 bool sd_conv_halo_applicable(const GemmArgs& a);
-int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up);
+int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up, int dt = 0);
 int sd_launch_conv3x3_halo(const GemmArgs& a, hipStream_t stream);
 
 // GroupNorm over NHWC (optionally a two-tensor channel concat) -> bf16 [B, HW, C1+C2]
@@ -49,6 +56,10 @@ struct GroupNormArgs {
     const bf16_t* x2 = nullptr; int C2 = 0;   // optional
     const float* gamma = nullptr; const float* beta = nullptr;  // [C1+C2]
     bf16_t* y = nullptr;
+    // out_fp8: y holds e4m3 bytes of sat(out * oscale), rows of Cpad >= C1+C2 bytes (a multiple of 128; the
+    // pad channels are written as zeros: they are the K tail of the fp8 GEMM / conv that consumes y)
+    int out_fp8 = 0, Cpad = 0;
+    float oscale = 1.0f;
     float* partial = nullptr;   // workspace of sd_groupnorm_scratch_bytes(): [B,nsplit,groups,2] partials + [B,groups,2] stats
     int B = 0, HW = 0, groups = 32, nsplit = 0;
     float eps = 1e-5f;
@@ -66,6 +77,11 @@ int sd_launch_pqconv(const float* x, const float* W, const float* bias, float* y
 
 int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
                         float eps, hipStream_t stream);
+// same, writing e4m3 bytes of sat(out * oscale) into rows of Cpad bytes (pad channels zero)
+int sd_launch_layernorm_fp8(const bf16_t* x, const float* gamma, const float* beta, void* y, int rows, int C, int Cpad,
+                            float eps, float oscale, hipStream_t stream);
+// bf16 [rows, C] -> e4m3 [rows, Cpad] of sat(x * scale), pad zero (tests; operands whose producer has no fp8 epilogue)
+int sd_launch_quantize_fp8(const bf16_t* x, void* y, long rows, int C, int Cpad, float scale, hipStream_t stream);
 
 struct AttnArgs {
     const bf16_t* Q = nullptr; long ldq = 0;  // [B, Nq, heads*D] rows with stride ldq

@@ -151,6 +151,15 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
             f[j] = f[j] * sc[j] + sf[j];
             if (a.silu) f[j] = silu_f(f[j]);
         }
+        if (a.out_fp8) {       // e4m3 bytes, rows of Cpad bytes; the owner of the last chunk zeroes the K-tail padding
+            char* yr = (char*)a.y + pix * a.Cpad;
+            const u32x2 o = {pack4fp8(f[0] * a.oscale, f[1] * a.oscale, f[2] * a.oscale, f[3] * a.oscale),
+                             pack4fp8(f[4] * a.oscale, f[5] * a.oscale, f[6] * a.oscale, f[7] * a.oscale)};
+            *(u32x2*)(yr + c0) = o;
+            if (ch == g.nchunks - 1)
+                for (int k = g.C; k < a.Cpad; k += 16) *(u32x4*)(yr + k) = u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
         u32x4 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
         *(u32x4*)(a.y + pix * g.C + c0) = o;
     };
@@ -216,15 +225,27 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
             f[j] = (f[j] - mean) * rstd * gm[j] + bt[j];
             if (a.silu) f[j] = silu_f(f[j]);
         }
-        u32x2 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
-        *(u32x2*)(a.y + (base + p) * C + c) = o;
+        if (a.out_fp8) {
+            *(unsigned*)((char*)a.y + (base + p) * a.Cpad + c) =
+                pack4fp8(f[0] * a.oscale, f[1] * a.oscale, f[2] * a.oscale, f[3] * a.oscale);
+        } else {
+            u32x2 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
+            *(u32x2*)(a.y + (base + p) * C + c) = o;
+        }
     }
+    if (a.out_fp8 && grp == a.groups - 1)       // K-tail padding of every pixel row
+        for (int i = tid; i < a.HW * ((a.Cpad - C) >> 4); i += 256) {
+            const int pc = (a.Cpad - C) >> 4, p = i / pc, k = i - p * pc;
+            *(u32x4*)((char*)a.y + (base + p) * a.Cpad + C + k * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
 }
 
 // one wave per token row; up to 3 chunks of 8 channels per lane (C <= 1536)
+// FP8: y holds e4m3 bytes of sat(out * oscale) in rows of Cpad bytes (the pad is zeroed)
+template <bool FP8>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                        int rows, int C, float eps) {
+                                                        int rows, int C, float eps, int Cpad, float oscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -255,6 +276,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     bf16_t* yr = y + (long)row * C;
+    char* yq = (char*)y + (long)row * Cpad;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int ch = lane + i * 64;
@@ -267,21 +289,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                 o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
                 o[j + 4] = (f[i][j + 4] - mean) * rstd * g1[j] + b1[j];
             }
-            u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
-            *(u32x4*)(yr + ch * 8) = ov;
+            if (FP8) {
+                const u32x2 ov = {pack4fp8(o[0] * oscale, o[1] * oscale, o[2] * oscale, o[3] * oscale),
+                                  pack4fp8(o[4] * oscale, o[5] * oscale, o[6] * oscale, o[7] * oscale)};
+                *(u32x2*)(yq + ch * 8) = ov;
+            } else {
+                u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+                *(u32x4*)(yr + ch * 8) = ov;
+            }
         }
     }
+    if (FP8 && lane < ((Cpad - C) >> 4)) *(u32x4*)(yq + C + lane * 16) = u32x4{0u, 0u, 0u, 0u};
 }
 
 // LayerNorm for C = 40 * LPR (320 / 640 / 1280: every SD-1.5 transformer width): LPR = 8 / 16 / 32 lanes share a
 // row, 5 chunks of 8 channels per lane, so all 64 lanes work (one wave per row leaves 24 of 64 lanes idle at
 // C = 320) and a wave covers 64 / LPR rows.  Lane j of a row group reads chunks j, j + LPR, ...: 16 * LPR contiguous
 // bytes per load instruction and row.  Two-pass statistics in registers, reductions by xor-shuffles inside the group.
-template <int LPR>
+template <int LPR, bool FP8>
 __global__ __launch_bounds__(256) void layernorm_grouped_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                                int rows, float eps) {
+                                                                int rows, float eps, float oscale) {
     constexpr int C = 40 * LPR, RPW = 64 / LPR;                  // channels, rows per wave
+    constexpr int CPAD = (C + 127) / 128 * 128;                  // fp8 row bytes (K tail of the consuming GEMM)
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -310,6 +340,7 @@ __global__ __launch_bounds__(256) void layernorm_grouped_kernel(const bf16_t* __
     const float rstd = rsqrtf(q / (float)C + eps);
     if (!live) return;
     bf16_t* yr = y + row * C;
+    char* yq = (char*)y + row * CPAD;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int ch = sub + i * LPR;
@@ -321,9 +352,33 @@ __global__ __launch_bounds__(256) void layernorm_grouped_kernel(const bf16_t* __
             o[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
             o[j + 4] = (f[i][j + 4] - mean) * rstd * g1[j] + b1[j];
         }
-        u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
-        *(u32x4*)(yr + ch * 8) = ov;
+        if (FP8) {
+            const u32x2 ov = {pack4fp8(o[0] * oscale, o[1] * oscale, o[2] * oscale, o[3] * oscale),
+                              pack4fp8(o[4] * oscale, o[5] * oscale, o[6] * oscale, o[7] * oscale)};
+            *(u32x2*)(yq + ch * 8) = ov;
+        } else {
+            u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+            *(u32x4*)(yr + ch * 8) = ov;
+        }
     }
+    if (FP8 && sub < ((CPAD - C) >> 4)) *(u32x4*)(yq + C + sub * 16) = u32x4{0u, 0u, 0u, 0u};
+}
+
+// bf16 [rows, C] -> e4m3 [rows, Cpad] of sat(x * scale); one 8-element chunk per thread, pad chunks zero
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* __restrict__ x, char* __restrict__ y, long rows,
+                                                           int C, int Cpad, float scale) {
+    const int cpr = Cpad >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cpr) return;
+    const long row = i / cpr;
+    const int c = (int)(i - row * cpr) * 8;
+    u32x2 o = {0u, 0u};
+    if (c < C) {
+        const u32x4 v = *(const u32x4*)(x + row * C + c);
+        o[0] = pack4fp8(bflo(v[0]) * scale, bfhi(v[0]) * scale, bflo(v[1]) * scale, bfhi(v[1]) * scale);
+        o[1] = pack4fp8(bflo(v[2]) * scale, bfhi(v[2]) * scale, bflo(v[3]) * scale, bfhi(v[3]) * scale);
+    }
+    *(u32x2*)(y + row * Cpad + c) = o;
 }
 
 // one wave per row; the row lives in registers (cols <= 4096)
@@ -396,6 +451,8 @@ int sd_groupnorm_nsplit(int B, int HW) {
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const int C = a.C1 + a.C2;
     SD_REQUIRE(a.x1 && a.y && a.gamma && a.beta && a.partial, "groupnorm: null operand");
+    SD_REQUIRE(!a.out_fp8 || (a.Cpad >= C && a.Cpad % 128 == 0 && C % 16 == 0 && a.oscale > 0.f),
+               "groupnorm fp8 out: Cpad=%d must be a multiple of 128 >= C=%d (C a multiple of 16)", a.Cpad, C);
     SD_REQUIRE(a.C1 % 8 == 0 && a.C2 % 8 == 0 && (a.C2 == 0 || a.x2), "groupnorm: C1=%d C2=%d must be multiples of 8", a.C1, a.C2);
     // an 8-channel chunk may straddle at most two groups: cpg >= 8, or cpg = 4 (aligned halves)
     SD_REQUIRE(a.groups > 0 && a.groups <= 64 && C % a.groups == 0 && (C / a.groups >= 8 || C / a.groups == 4),
@@ -417,21 +474,53 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     return 0;
 }
 
-int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
-                        float eps, hipStream_t stream) {
+static int launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C, float eps,
+                            bool fp8, int Cpad, float oscale, hipStream_t stream) {
     SD_REQUIRE(x && y && gamma && beta, "layernorm: null operand");
     SD_REQUIRE(C % 8 == 0 && C > 0 && C <= 1536, "layernorm: C=%d must be a multiple of 8 and <= 1536", C);
     SD_REQUIRE(rows > 0, "layernorm: no rows");
+    SD_REQUIRE(!fp8 || (Cpad == (C + 127) / 128 * 128 && C % 16 == 0 && oscale > 0.f && Cpad - C <= 64 * 16),
+               "layernorm fp8 out: Cpad=%d must be C=%d rounded up to 128 (C a multiple of 16)", Cpad, C);
     auto grouped = [&](auto kern, int lpr) {
         const int rows_per_block = 4 * (64 / lpr);
         hipLaunchKernelGGL(kern, dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), 0, stream, x, gamma, beta, y,
-                           rows, eps);
+                           rows, eps, oscale);
     };
-    if (C == 320) grouped(layernorm_grouped_kernel<8>, 8);
-    else if (C == 640) grouped(layernorm_grouped_kernel<16>, 16);
-    else if (C == 1280) grouped(layernorm_grouped_kernel<32>, 32);
-    else
-        hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
+    if (fp8) {
+        if (C == 320) grouped(layernorm_grouped_kernel<8, true>, 8);
+        else if (C == 640) grouped(layernorm_grouped_kernel<16, true>, 16);
+        else if (C == 1280) grouped(layernorm_grouped_kernel<32, true>, 32);
+        else
+            hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C,
+                               eps, Cpad, oscale);
+    } else {
+        if (C == 320) grouped(layernorm_grouped_kernel<8, false>, 8);
+        else if (C == 640) grouped(layernorm_grouped_kernel<16, false>, 16);
+        else if (C == 1280) grouped(layernorm_grouped_kernel<32, false>, 32);
+        else
+            hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C,
+                               eps, C, 1.0f);
+    }
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
+                        float eps, hipStream_t stream) {
+    return launch_layernorm(x, gamma, beta, y, rows, C, eps, false, C, 1.0f, stream);
+}
+
+int sd_launch_layernorm_fp8(const bf16_t* x, const float* gamma, const float* beta, void* y, int rows, int C, int Cpad,
+                            float eps, float oscale, hipStream_t stream) {
+    return launch_layernorm(x, gamma, beta, (bf16_t*)y, rows, C, eps, true, Cpad, oscale, stream);
+}
+
+int sd_launch_quantize_fp8(const bf16_t* x, void* y, long rows, int C, int Cpad, float scale, hipStream_t stream) {
+    SD_REQUIRE(x && y && rows > 0, "quantize_fp8: null operand");
+    SD_REQUIRE(C % 8 == 0 && Cpad % 8 == 0 && Cpad >= C && scale > 0.f, "quantize_fp8: C=%d Cpad=%d", C, Cpad);
+    const long n = rows * (Cpad >> 3);
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, (char*)y, rows, C,
+                       Cpad, scale);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

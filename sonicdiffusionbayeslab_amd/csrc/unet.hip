@@ -30,7 +30,7 @@ void sd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sd_last_error(void) { return g_err; }
-extern "C" int sd_abi_version(void) { return 1; }
+extern "C" int sd_abi_version(void) { return 2; }   // 2: sd_unet_config.weight_dtype, fp8 operator entry points
 
 static void* g_zero_page = nullptr;
 // grow-only device scratch for the operator-level entry points (tests / micro-benchmarks only;
@@ -105,6 +105,12 @@ struct Op {
     float scale = 0.f;
     long wbs = 0;                 // per-sample W: batch stride (elements), rows per sample, softmax width
     int rpb = 0, sm_valid = 0;
+    // fp8-e4m3 operands (SD_DTYPE_FP8_E4M3): this op's X and W are e4m3 (K / Cin padded to 128), wsc = offset of
+    // the per-output-channel weight scales, xs = activation scale of its input; out_fp8: the op WRITES e4m3
+    // (rows of Cpad bytes) with scale os.  Kalg: unpadded contraction length (algorithmic FLOPs).
+    int dt = 0, out_fp8 = 0, Cpad = 0, Kalg = 0;
+    size_t wsc = NOFF;
+    float xs = 1.f, os = 1.f;
     int nwrap = 0;
     Wrap wraps[3];
 };
@@ -146,6 +152,8 @@ struct sd_unet {
     char* dweights = nullptr;
     bool finalized = false;
     bool debug_taps = false;
+    bool fp8 = false;                  // cfg.weight_dtype == SD_DTYPE_FP8_E4M3
+    float s_norm = 8.f, s_ff = 2.f;    // fp8 activation scales (GroupNorm / LayerNorm outputs, GEGLU outputs)
     std::map<std::pair<int, int>, Plan> plans;
     std::unordered_map<std::string, long> tproj_off;  // resnet prefix -> float index into tproj vector
     long tproj_total = 0;
@@ -337,8 +345,70 @@ inline unsigned short f32_to_bf16_host(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// f32 -> OCP e4m3fn byte, round to nearest even, saturating at +-448 (no infinities; 0x7f = NaN)
+inline unsigned char f32_to_e4m3_host(float f) {
+    if (f != f) return 0x7f;
+    const unsigned char sign = std::signbit(f) ? 0x80 : 0;
+    const float a = fabsf(f);
+    if (a >= 448.f) return sign | 0x7e;
+    if (a < 0.015625f) {                                  // subnormal range: multiples of 2^-9
+        const int q = (int)nearbyintf(a * 512.f);         // 0..8 (8 = the smallest normal)
+        return sign | (unsigned char)q;
+    }
+    int e;
+    const float m = frexpf(a, &e);                        // a = m * 2^e, m in [0.5, 1)
+    int ex = e - 1;
+    int q = (int)nearbyintf((m * 2.f - 1.f) * 8.f);       // 0..8
+    if (q == 8) { q = 0; ++ex; }
+    const int biased = ex + 7;
+    if (biased > 15 || (biased == 15 && q == 7)) return sign | 0x7e;
+    return sign | (unsigned char)((biased << 3) | q);
+}
+
 struct Packer {
     sd_unet* u;
+    // rows [N][K] fp32 -> e4m3 [N][Kp] (K zero padded to Kp) + one fp32 scale per row (amax / 448)
+    void quant_rows(const std::string& key, const float* w, int N, int K, int Kp) {
+        size_t off = alloc(key + ".fp8", (size_t)N * Kp);
+        size_t soff = alloc(key + ".scale", (size_t)N * 4);
+        unsigned char* o = u->hblob.data() + off;
+        float* sc = (float*)(u->hblob.data() + soff);
+        for (int n = 0; n < N; ++n) {
+            float amax = 0.f;
+            for (int k = 0; k < K; ++k) amax = std::max(amax, fabsf(w[(size_t)n * K + k]));
+            const float scale = amax > 0.f ? amax / 448.f : 1.f;
+            sc[n] = scale;
+            const float inv = 1.f / scale;
+            for (int k = 0; k < K; ++k) o[(size_t)n * Kp + k] = f32_to_e4m3_host(w[(size_t)n * K + k] * inv);
+            for (int k = K; k < Kp; ++k) o[(size_t)n * Kp + k] = 0;
+        }
+    }
+    void fp8_same(const std::string& n, int N, int K) { quant_rows(n, P(n).data(), N, K, (K + 127) / 128 * 128); }
+    void fp8_concat_rows(const std::string& key, const std::vector<std::string>& names, int K) {
+        std::vector<float> all;
+        for (auto& n : names) all.insert(all.end(), P(n).begin(), P(n).end());
+        quant_rows(key, all.data(), (int)(all.size() / K), K, (K + 127) / 128 * 128);
+    }
+    // OIHW -> e4m3 [O][Ip/128][tap][128] (Ip = I padded to 128) + per-output-channel scale
+    void conv3_fp8(const std::string& n, int O, int I) {
+        const auto& d = P(n);
+        const int Ip = (I + 127) / 128 * 128;
+        size_t off = alloc(n + ".fp8", (size_t)O * 9 * Ip);
+        size_t soff = alloc(n + ".scale", (size_t)O * 4);
+        unsigned char* o = u->hblob.data() + off;
+        float* sc = (float*)(u->hblob.data() + soff);
+        memset(o, 0, (size_t)O * 9 * Ip);
+        for (int oc = 0; oc < O; ++oc) {
+            float amax = 0.f;
+            for (int k = 0; k < I * 9; ++k) amax = std::max(amax, fabsf(d[(size_t)oc * I * 9 + k]));
+            const float scale = amax > 0.f ? amax / 448.f : 1.f, inv = 1.f / scale;
+            sc[oc] = scale;
+            for (int ic = 0; ic < I; ++ic)
+                for (int t = 0; t < 9; ++t)
+                    o[(((size_t)oc * (Ip / 128) + ic / 128) * 9 + t) * 128 + (ic % 128)] =
+                        f32_to_e4m3_host(d[((size_t)oc * I + ic) * 9 + t] * inv);
+        }
+    }
     const std::vector<float>& P(const std::string& n) { return u->params[u->pindex.at(n)].data; }
     size_t alloc(const std::string& key, size_t bytes) {
         size_t off = (u->hblob.size() + 255) / 256 * 256;
@@ -389,30 +459,44 @@ struct Packer {
         const auto& w = P(t + "ff.net.0.proj.weight");
         const auto& b = P(t + "ff.net.0.proj.bias");
         const int H = 4 * C;
-        size_t off = alloc(t + "ff.geglu.weight", w.size() * 2);
-        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
         size_t boff = alloc(t + "ff.geglu.bias", b.size() * 4);
         float* bo = (float*)(u->hblob.data() + boff);
+        std::vector<float> perm(u->fp8 ? w.size() : 0);
+        unsigned short* o = nullptr;
+        if (!u->fp8) o = (unsigned short*)(u->hblob.data() + alloc(t + "ff.geglu.weight", w.size() * 2));
         for (int r = 0; r < 2 * H; ++r) {
             const int grp = r / 32, within = r % 32;
             const int src = within < 16 ? grp * 16 + within : H + grp * 16 + (within - 16);
-            for (int k = 0; k < C; ++k) o[(size_t)r * C + k] = f32_to_bf16_host(w[(size_t)src * C + k]);
-            bo[r] = b[src];
+            if (u->fp8) memcpy(&perm[(size_t)r * C], &w[(size_t)src * C], (size_t)C * 4);
+            else for (int k = 0; k < C; ++k) o[(size_t)r * C + k] = f32_to_bf16_host(w[(size_t)src * C + k]);
+            ((float*)(u->hblob.data() + boff))[r] = b[src];
         }
+        (void)bo;
+        if (u->fp8) quant_rows(t + "ff.geglu.weight", perm.data(), 2 * H, C, (C + 127) / 128 * 128);
     }
     void resnet(const std::string& p, int cin, int cout) {
         f32(p + "norm1.weight"); f32(p + "norm1.bias");
-        conv3(p + "conv1.weight", cout, cin); f32(p + "conv1.bias");
+        f32(p + "conv1.bias");
         f32(p + "norm2.weight"); f32(p + "norm2.bias");
-        conv3(p + "conv2.weight", cout, cout); f32(p + "conv2.bias");
+        f32(p + "conv2.bias");
+        if (u->fp8) { conv3_fp8(p + "conv1.weight", cout, cin); conv3_fp8(p + "conv2.weight", cout, cout); }
+        else { conv3(p + "conv1.weight", cout, cin); conv3(p + "conv2.weight", cout, cout); }
         if (cin != cout) { bf16_same(p + "conv_shortcut.weight"); f32(p + "conv_shortcut.bias"); }
     }
     void transformer(const std::string& p, int c) {
         f32(p + "norm.weight"); f32(p + "norm.bias");
-        bf16_same(p + "proj_in.weight"); f32(p + "proj_in.bias");
+        f32(p + "proj_in.bias");
         const std::string t = p + "transformer_blocks.0.";
         for (int i = 1; i <= 3; ++i) { f32(t + "norm" + std::to_string(i) + ".weight"); f32(t + "norm" + std::to_string(i) + ".bias"); }
-        concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"});
+        if (u->fp8) {
+            fp8_same(p + "proj_in.weight", c, c);
+            fp8_concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"}, c);
+            fp8_same(t + "ff.net.2.weight", c, 4 * c);
+        } else {
+            bf16_same(p + "proj_in.weight");
+            concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"});
+            bf16_same(t + "ff.net.2.weight");
+        }
         bf16_same(t + "attn1.to_out.0.weight"); f32(t + "attn1.to_out.0.bias");
         bf16_same(t + "attn2.to_q.weight");
         {   // to_q transposed ([in][out]): the W operand of A^T = (scale K_h) . W_q,h of the folded cross-attention
@@ -425,7 +509,7 @@ struct Packer {
         concat_rows(t + "attn2.kv.weight", {t + "attn2.to_k.weight", t + "attn2.to_v.weight"});
         bf16_same(t + "attn2.to_out.0.weight"); f32(t + "attn2.to_out.0.bias");
         geglu(t, c);
-        bf16_same(t + "ff.net.2.weight"); f32(t + "ff.net.2.bias");
+        f32(t + "ff.net.2.bias");
         bf16_same(p + "proj_out.weight"); f32(p + "proj_out.bias");
     }
 };
@@ -606,41 +690,54 @@ struct Builder {
         pl.ops.push_back(op);
         return pl.ops.back();
     }
-    int gn(int x1, int c1, int x2, int c2, int hw, const std::string& g, const std::string& b, float eps, int silu) {
+    static int pad128(int c) { return (c + 127) / 128 * 128; }
+    // fq: the output feeds an fp8 contraction -> e4m3 rows of pad128(C) bytes, scaled by the handle's norm scale
+    int gn(int x1, int c1, int x2, int c2, int hw, const std::string& g, const std::string& b, float eps, int silu,
+           bool fq = false) {
         Op o; o.kind = OP_GN; o.x1 = x1; o.C1 = c1; o.x2 = x2; o.C2 = c2; o.HW = hw; o.B = UB;
         o.g = W(g); o.be = W(b); o.eps = eps; o.silu = silu;
         o.nsplit = sd_groupnorm_nsplit(UB, hw);
         o.aux = tensor(sd_groupnorm_scratch_bytes(UB, hw, u->cfg.norm_num_groups));
-        o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
+        if (fq) { o.out_fp8 = 1; o.Cpad = pad128(c1 + c2); o.os = u->s_norm; o.out = tensor((size_t)UB * hw * o.Cpad); }
+        else o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
         push(o);
         return o.out;
     }
+    // fq: x is an e4m3 tensor of pad128(cin) channels written with activation scale xs
     int conv3(int x, int hin, int cin, int cout, int stride, int up, const std::string& w, const std::string& b,
-              long b2idx, int b2t, int r) {
+              long b2idx, int b2t, int r, bool fq = false) {
         Op o; o.kind = OP_CONV3; o.x1 = x; o.B = UB; o.Hin = hin; o.Win = hin; o.Cin = cin; o.N = cout;
         o.stride = stride; o.up = up;
         const int hv = hin << up;
         o.Hout = o.Wout = (hv + 2 - 3) / stride + 1;
-        o.M = UB * o.Hout * o.Wout; o.K = 9 * cin;
-        o.w = W(w); o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
-        o.splitk = sd_conv3x3_splitk(o.M, o.N, cin, hin, hin, stride, up);
+        o.M = UB * o.Hout * o.Wout; o.K = 9 * cin; o.Kalg = o.K;
+        o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
+        if (fq) { o.dt = 1; o.Cin = pad128(cin); o.K = 9 * o.Cin; o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = u->s_norm; }
+        else o.w = W(w);
+        o.splitk = sd_conv3x3_splitk(o.M, o.N, o.Cin, hin, hin, stride, up, o.dt);
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * o.M * o.N * 4);
         o.out = tensor((size_t)o.M * cout * 2);
         push(o);
         return o.out;
     }
-    int gemm(int x1, int k1, int x2, int k2, int M, int N, const std::string& w, const std::string& b, int r, int epi) {
-        Op o; o.kind = OP_GEMM; o.x1 = x1; o.x2 = x2; o.K1 = k1; o.K = k1 + k2; o.M = M; o.N = N; o.epi = epi;
-        o.w = W(w); o.b = b.empty() ? NOFF : W(b); o.r = r;
-        o.splitk = epi ? 1 : sd_gemm_splitk(M, N, o.K);
+    // fq = activation scale of an e4m3 x1 (0 = bf16 operands); oq = scale of an e4m3 OUTPUT (GEGLU epilogue only)
+    int gemm(int x1, int k1, int x2, int k2, int M, int N, const std::string& w, const std::string& b, int r, int epi,
+             float fq = 0.f, float oq = 0.f) {
+        Op o; o.kind = OP_GEMM; o.x1 = x1; o.x2 = x2; o.K1 = k1; o.K = k1 + k2; o.Kalg = o.K; o.M = M; o.N = N; o.epi = epi;
+        o.b = b.empty() ? NOFF : W(b); o.r = r;
+        if (fq > 0.f) { o.dt = 1; o.K = o.K1 = pad128(k1); o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = fq; }
+        else o.w = W(w);
+        o.splitk = epi ? 1 : sd_gemm_splitk(M, N, o.dt ? o.K / 2 : o.K);     // the heuristic counts 128-byte K tiles
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * M * N * 4);
-        o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
+        if (oq > 0.f) { o.out_fp8 = 1; o.os = oq; o.Cpad = pad128(N / 2); o.out = tensor((size_t)M * o.Cpad); }
+        else o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
         push(o);
         return o.out;
     }
-    int ln(int x, int M, int C, const std::string& g, const std::string& b) {
+    int ln(int x, int M, int C, const std::string& g, const std::string& b, bool fq = false) {
         Op o; o.kind = OP_LN; o.x1 = x; o.M = M; o.N = C; o.g = W(g); o.be = W(b); o.eps = 1e-5f;
-        o.out = tensor((size_t)M * C * 2);
+        if (fq) { o.out_fp8 = 1; o.Cpad = pad128(C); o.os = u->s_norm; o.out = tensor((size_t)M * o.Cpad); }
+        else o.out = tensor((size_t)M * C * 2);
         push(o);
         return o.out;
     }
@@ -655,21 +752,24 @@ struct Builder {
     // ResnetBlock2D (A.3); input may be a virtual channel concat [x1 | x2]
     int resnet(const std::string& p, int x1, int c1, int x2, int c2, int cout, int res, int tproj_t) {
         const int hw = res * res, cin = c1 + c2, M = UB * hw;
-        int t1 = gn(x1, c1, x2, c2, hw, p + "norm1.weight", p + "norm1.bias", u->cfg.norm_eps, 1);
-        int t2 = conv3(t1, res, cin, cout, 1, 0, p + "conv1.weight", p + "conv1.bias", u->tproj_off.at(p), tproj_t, -1);
-        int t3 = gn(t2, cout, -1, 0, hw, p + "norm2.weight", p + "norm2.bias", u->cfg.norm_eps, 1);
+        const bool fq = u->fp8;          // GroupNorm+SiLU writes e4m3, both 3x3 convs contract in fp8
+        int t1 = gn(x1, c1, x2, c2, hw, p + "norm1.weight", p + "norm1.bias", u->cfg.norm_eps, 1, fq);
+        int t2 = conv3(t1, res, cin, cout, 1, 0, p + "conv1.weight", p + "conv1.bias", u->tproj_off.at(p), tproj_t, -1, fq);
+        int t3 = gn(t2, cout, -1, 0, hw, p + "norm2.weight", p + "norm2.bias", u->cfg.norm_eps, 1, fq);
         int sc = x1;
         if (cin != cout) sc = gemm(x1, c1, x2, c2, M, cout, p + "conv_shortcut.weight", p + "conv_shortcut.bias", -1, 0);
-        return conv3(t3, res, cout, cout, 1, 0, p + "conv2.weight", p + "conv2.bias", 0, -1, sc);
+        return conv3(t3, res, cout, cout, 1, 0, p + "conv2.weight", p + "conv2.bias", 0, -1, sc, fq);
     }
     // Transformer2DModel with one BasicTransformerBlock (A.4)
     int transformer(const std::string& p, int x, int C, int res) {
         const int hw = res * res, M = UB * hw, L = u->cfg.context_len;
         const std::string t = p + "transformer_blocks.0.";
-        int g = gn(x, C, -1, 0, hw, p + "norm.weight", p + "norm.bias", 1e-6f, 0);
-        int h0 = gemm(g, C, -1, 0, M, C, p + "proj_in.weight", p + "proj_in.bias", -1, 0);
-        int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias");
-        int qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0);
+        const bool fq = u->fp8;
+        const float sn = fq ? u->s_norm : 0.f, sf = fq ? u->s_ff : 0.f;
+        int g = gn(x, C, -1, 0, hw, p + "norm.weight", p + "norm.bias", 1e-6f, 0, fq);
+        int h0 = gemm(g, C, -1, 0, M, C, p + "proj_in.weight", p + "proj_in.bias", -1, 0, sn);
+        int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias", fq);
+        int qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0, sn);
         int a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
         int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
@@ -702,9 +802,9 @@ struct Builder {
             int a2 = attn(q2, 0, C, kv, 0, C, 2 * C, hw, L, C);
             h2 = gemm(a2, C, -1, 0, M, C, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", h1, 0);
         }
-        int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias");
-        int ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1);
-        int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0);
+        int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias", fq);
+        int ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, sn, sf);
+        int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, sf);
         return gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
     }
 
@@ -1020,6 +1120,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.gamma = (const float*)(wb + o.g); a.beta = (const float*)(wb + o.be);
             a.y = (bf16_t*)T(o.out); a.partial = (float*)T(o.aux);
             a.B = o.B; a.HW = o.HW; a.groups = u->cfg.norm_num_groups; a.nsplit = o.nsplit; a.eps = o.eps; a.silu = o.silu;
+            a.out_fp8 = o.out_fp8; a.Cpad = o.Cpad; a.oscale = o.os;
             return sd_launch_groupnorm(a, stream);
         }
         case OP_CONV3: {
@@ -1030,6 +1131,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.M = o.M; a.N = o.N; a.K = o.K; a.K1 = o.K;
             a.Hin = o.Hin; a.Win = o.Win; a.Cin = o.Cin; a.Hout = o.Hout; a.Wout = o.Wout; a.stride = o.stride; a.up = o.up;
             a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
+            if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
             return sd_launch_conv3x3(a, stream);
         }
         case OP_GEMM: {
@@ -1042,9 +1144,14 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.ldc = o.ldc_o ? o.ldc_o : (o.epi == 1 ? o.N / 2 : o.N);
             a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
             a.w_batch_stride = o.wbs; a.rows_per_batch = o.rpb; a.sm_valid = o.sm_valid;
+            if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
+            if (o.out_fp8) { a.out_fp8 = 1; a.oscale = o.os; a.ldc = o.Cpad; }
             return sd_launch_gemm(a, o.epi, stream);
         }
         case OP_LN:
+            if (o.out_fp8)
+                return sd_launch_layernorm_fp8((const bf16_t*)T(o.x1), (const float*)(wb + o.g), (const float*)(wb + o.be),
+                                               T(o.out), o.M, o.N, o.Cpad, o.eps, o.os, stream);
             return sd_launch_layernorm((const bf16_t*)T(o.x1), (const float*)(wb + o.g), (const float*)(wb + o.be),
                                        (bf16_t*)T(o.out), o.M, o.N, o.eps, stream);
         case OP_ATTN: {
@@ -1099,8 +1206,14 @@ extern "C" int sd_unet_create(const sd_unet_config* cfg, sd_unet** out) {
     SD_REQUIRE(cfg->cross_attention_dim % 64 == 0, "sd_unet_create: cross_attention_dim must be a multiple of 64");
     SD_REQUIRE(cfg->sample_size % (1 << (cfg->num_levels - 1)) == 0, "sd_unet_create: sample_size not divisible");
     SD_REQUIRE(cfg->context_len >= 1, "sd_unet_create: context_len");
+    SD_REQUIRE(cfg->weight_dtype == SD_DTYPE_BF16 || cfg->weight_dtype == SD_DTYPE_FP8_E4M3,
+               "sd_unet_create: weight_dtype %d (0 = bf16, 1 = fp8 e4m3)", cfg->weight_dtype);
+    SD_REQUIRE(cfg->fp8_act_scale_norm >= 0.f && cfg->fp8_act_scale_ff >= 0.f, "sd_unet_create: negative fp8 activation scale");
     sd_unet* u = new sd_unet();   // no device work here: parameter enumeration also runs on a CPU-only box
     u->cfg = *cfg;
+    u->fp8 = cfg->weight_dtype == SD_DTYPE_FP8_E4M3;
+    if (cfg->fp8_act_scale_norm > 0.f) u->s_norm = cfg->fp8_act_scale_norm;
+    if (cfg->fp8_act_scale_ff > 0.f) u->s_ff = cfg->fp8_act_scale_ff;
     u->debug_taps = getenv("SD_DEBUG_TAPS") != nullptr;
     enumerate_params(u);
     *out = u;
@@ -1313,10 +1426,12 @@ static void op_work(const Op& o, double* flops, double* bytes) {
     *flops = 0; *bytes = 0;
     switch (o.kind) {
         case OP_CONV3:
-        case OP_GEMM:
-            *flops = 2.0 * o.M * o.N * o.K;
-            *bytes = 2.0 * ((double)o.M * o.K + (double)o.N * o.K + (double)o.M * (o.epi == 1 ? o.N / 2 : o.N));
+        case OP_GEMM: {
+            const double K = o.Kalg ? o.Kalg : o.K, esz = o.dt ? 1.0 : 2.0;
+            *flops = 2.0 * o.M * o.N * K;
+            *bytes = esz * ((double)o.M * K + (double)o.N * K) + (o.out_fp8 ? 1.0 : 2.0) * (double)o.M * (o.epi == 1 ? o.N / 2 : o.N);
             break;
+        }
         case OP_ATTN:
             *flops = 4.0 * o.B * o.heads * (double)o.Nq * o.Nk * o.D;
             *bytes = 2.0 * o.B * o.heads * o.D * (2.0 * o.Nq + 2.0 * o.Nk);
@@ -1334,8 +1449,9 @@ static void op_work(const Op& o, double* flops, double* bytes) {
 
 extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
                                         float timestep, float* eps_out, void* workspace, long long workspace_bytes,
-                                        int cache_mode, int cache_branch_id, double kind_ms[16], long long kind_launches[16],
-                                        double kind_flops[16], double kind_bytes[16]) {
+                                        int cache_mode, int cache_branch_id, double kind_ms[SD_PROFILE_KINDS],
+                                        long long kind_launches[SD_PROFILE_KINDS], double kind_flops[SD_PROFILE_KINDS],
+                                        double kind_bytes[SD_PROFILE_KINDS]) {
     SD_REQUIRE(latents && eps_out && workspace && kind_ms && kind_launches && kind_flops && kind_bytes,
                "forward_profiled: null argument");
     SD_REQUIRE(latent_batch > 0 && unet_batch % latent_batch == 0, "forward_profiled: bad batch");
@@ -1358,14 +1474,15 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
         if (rc) break;
     }
     SD_CHECK_HIP(hipStreamSynchronize(st));
-    for (int k = 0; k < 16; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; kind_flops[k] = 0; kind_bytes[k] = 0; }
+    for (int k = 0; k < SD_PROFILE_KINDS; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; kind_flops[k] = 0; kind_bytes[k] = 0; }
     for (size_t j = 0; j < which.size(); ++j) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1]);
         const Op& o = pl->ops[which[j]];
         double fl, by;
         op_work(o, &fl, &by);
-        kind_ms[o.kind] += ms; kind_launches[o.kind] += 1; kind_flops[o.kind] += fl; kind_bytes[o.kind] += by;
+        const int kd = o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind;
+        kind_ms[kd] += ms; kind_launches[kd] += 1; kind_flops[kd] += fl; kind_bytes[kd] += by;
     }
     for (auto e : ev) (void)hipEventDestroy(e);
     return rc;
@@ -1488,4 +1605,66 @@ extern "C" int sd_op_time_embedding(void* stream, float t, const void* W1, const
     if ((rc = sd_launch_timestep_sinusoid(t, scratch, dim_in, (hipStream_t)stream))) return rc;
     if ((rc = sd_launch_gemv(scratch, (const bf16_t*)W1, b1, scratch + dim_in, dim, dim_in, 0, (hipStream_t)stream))) return rc;
     return sd_launch_gemv(scratch + dim_in, (const bf16_t*)W2, b2, temb, dim, dim, 1, (hipStream_t)stream);
+}
+
+// ---- fp8-e4m3 operand path, operator level (parity tests of SD_DTYPE_FP8_E4M3) ---------------------------------
+extern "C" int sd_op_gemm_fp8(void* stream, const void* X, long long ldx, const void* W, const float* wscale, float xscale,
+                              const float* bias, const void* R, long long ldr, void* C, long long ldc, int M, int N, int K,
+                              int epi, int out_fp8, float oscale) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(epi == 0 || epi == 1, "sd_op_gemm_fp8: epi %d (0 = std, 1 = GEGLU)", epi);
+    SD_REQUIRE(xscale > 0.f && (!out_fp8 || (epi == 1 && oscale > 0.f)), "sd_op_gemm_fp8: bad scales / fp8 output needs the GEGLU epilogue");
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.ldr = ldr;
+    a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
+    a.dt = 1; a.wscale = wscale; a.xscale_inv = 1.0f / xscale; a.out_fp8 = out_fp8; a.oscale = oscale;
+    a.splitk = epi ? 1 : sd_gemm_splitk(M, N, K / 2);
+    if (a.splitk > 1) {
+        a.slab = (float*)op_scratch((size_t)a.splitk * M * N * 4);
+        SD_REQUIRE(a.slab, "sd_op_gemm_fp8: cannot allocate split-K scratch");
+    }
+    return sd_launch_gemm(a, epi, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_conv3x3_fp8(void* stream, const void* X, const void* W, const float* wscale, float xscale,
+                                 const float* bias, const float* bias2, const void* R, void* Y, int B, int Hin, int Win,
+                                 int Cin, int Cout, int stride, int upsample) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(stride == 1 || stride == 2, "conv3x3 fp8: stride %d", stride);
+    SD_REQUIRE(xscale > 0.f, "conv3x3 fp8: activation scale");
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = Cout;
+    a.C = (bf16_t*)Y; a.ldc = Cout;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = stride; a.up = upsample ? 1 : 0;
+    a.Hout = ((Hin << a.up) + 2 - 3) / stride + 1; a.Wout = ((Win << a.up) + 2 - 3) / stride + 1;
+    a.M = B * a.Hout * a.Wout; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page;
+    a.dt = 1; a.wscale = wscale; a.xscale_inv = 1.0f / xscale;
+    a.splitk = sd_conv3x3_splitk(a.M, a.N, Cin, Hin, Win, stride, a.up, 1);
+    if (a.splitk > 1) {
+        a.slab = (float*)op_scratch((size_t)a.splitk * a.M * a.N * 4);
+        SD_REQUIRE(a.slab, "sd_op_conv3x3_fp8: cannot allocate split-K scratch");
+    }
+    return sd_launch_conv3x3(a, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_groupnorm_fp8(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                                   const float* beta, void* y, int B, int HW, int groups, float eps, int silu, int Cpad,
+                                   float oscale) {
+    GroupNormArgs a;
+    a.x1 = (const bf16_t*)x1; a.C1 = C1; a.x2 = (const bf16_t*)x2; a.C2 = C2; a.gamma = gamma; a.beta = beta;
+    a.y = (bf16_t*)y; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
+    a.out_fp8 = 1; a.Cpad = Cpad; a.oscale = oscale;
+    a.nsplit = sd_groupnorm_nsplit(B, HW);
+    a.partial = (float*)op_scratch(sd_groupnorm_scratch_bytes(B, HW, groups));
+    SD_REQUIRE(a.partial, "sd_op_groupnorm_fp8: cannot allocate scratch");
+    return sd_launch_groupnorm(a, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_layernorm_fp8(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows,
+                                   int C, int Cpad, float eps, float oscale) {
+    return sd_launch_layernorm_fp8((const bf16_t*)x, gamma, beta, y, rows, C, Cpad, eps, oscale, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_quantize_fp8(void* stream, const void* x_bf16, void* y_fp8, long long rows, int C, int Cpad, float scale) {
+    return sd_launch_quantize_fp8((const bf16_t*)x_bf16, y_fp8, (long)rows, C, Cpad, scale, (hipStream_t)stream);
 }

@@ -58,12 +58,16 @@ class BaseMethod(ABC):
 
     def setup_model(self):
         model_name = self.config.model.model_name
+        extra = {}
+        if self.config.model.get("weight_dtype", None) is not None:      # key of this build: "bf16" | "fp8"
+            extra["weight_dtype"] = self.config.model.weight_dtype
         self.model = models_registry[model_name].from_pretrained(
             self.config.model.pretrained_model,
             timestamps=self.config.model.get("timestamps", None),
             safety_checker=None,
             requires_safety_checker=False,
             torch_dtype=torch.float16,
+            **extra,
         )
         self.model.to(self.device)
 

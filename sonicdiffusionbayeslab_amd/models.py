@@ -73,8 +73,11 @@ class StableDiffusionModel:
 
     def __init__(self, unet_config: Optional[UNetConfig] = None, state_dict=None, scheduler=None,
                  text_encoder: Optional[Callable] = None, vae_decoder: Optional[Callable] = None,
-                 weights_seed: int = 1234, source: str = "synthetic", clip_dir: Optional[str] = None):
+                 weights_seed: int = 1234, source: str = "synthetic", clip_dir: Optional[str] = None,
+                 weight_dtype: Optional[str] = None):
         self.unet_config = unet_config or UNetConfig()
+        # "bf16" | "fp8": operand type of the UNet's MFMA contractions (YAML model.weight_dtype, or SD_AMD_WEIGHT_DTYPE)
+        self.weight_dtype = weight_dtype or os.environ.get("SD_AMD_WEIGHT_DTYPE", "bf16")
         self._state_dict = state_dict
         self._weights_seed = weights_seed
         self.weights_source = source
@@ -122,7 +125,10 @@ class StableDiffusionModel:
                 else:
                     _fuse_synthetic_lora(sd, *item)
                     self.weights_source += f" + SYNTHETIC low-rank stand-in for a hub LoRA (seed={item[0]}) fused"
-            self.unet = HipUNet2DConditionModel(self.unet_config, sd, device="cuda:%d" % torch.cuda.current_device())
+            self.unet = HipUNet2DConditionModel(self.unet_config, sd, device="cuda:%d" % torch.cuda.current_device(),
+                                                weight_dtype=self.weight_dtype)
+            if self.unet.weight_dtype != "bf16":
+                self.weights_source += f" [{self.unet.weight_dtype} weights + activations in the conv / FF / QKV contractions]"
             self._state_dict = None
 
     def _ensure_vae(self):

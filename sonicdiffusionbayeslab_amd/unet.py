@@ -20,8 +20,12 @@ from .weights import UNetConfig, param_shapes
 CACHE_OFF, CACHE_FULL_AND_STORE, CACHE_SKIP = 0, 1, 2
 
 
-def _c_config(cfg: UNetConfig) -> _lib.SdUnetConfig:
+def _c_config(cfg: UNetConfig, weight_dtype: str = "bf16", fp8_act_scales=(0.0, 0.0)) -> _lib.SdUnetConfig:
     c = _lib.SdUnetConfig()
+    if weight_dtype not in _lib.DTYPES:
+        raise ValueError(f"weight_dtype {weight_dtype!r}: one of {sorted(_lib.DTYPES)}")
+    c.weight_dtype = _lib.DTYPES[weight_dtype]
+    c.fp8_act_scale_norm, c.fp8_act_scale_ff = float(fp8_act_scales[0]), float(fp8_act_scales[1])
     c.sample_size, c.in_channels, c.out_channels = cfg.sample_size, cfg.in_channels, cfg.out_channels
     c.num_levels = len(cfg.block_out_channels)
     for i, v in enumerate(cfg.block_out_channels):
@@ -37,7 +41,11 @@ class HipUNet2DConditionModel:
     """SD-1.5 UNet running on libsdhip.  ``config`` mirrors the diffusers attributes the
     reference loop reads (``in_channels``, ``sample_size``, ``time_cond_proj_dim``)."""
 
-    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0"):
+    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0",
+                 weight_dtype: str = "bf16", fp8_act_scales=(0.0, 0.0)):
+        """``weight_dtype="fp8"``: OCP e4m3 weights (per-output-channel scales) and e4m3 activations with static
+        per-tensor scales for the resnet 3x3 convs, proj_in, the self-attention QKV projection and the feed-forward
+        GEMMs (include/sd_hip.h::sd_unet_config.weight_dtype; BASELINE configs[4])."""
         if not torch.cuda.is_available():
             raise _lib.SdHipError("HipUNet2DConditionModel needs an MI355X (no CPU fallback exists)")
         self.config = config
@@ -46,7 +54,8 @@ class HipUNet2DConditionModel:
         self._lib = _lib.load()
         self._handle = C.c_void_p()
         torch.cuda.set_device(self.device)
-        ccfg = _c_config(config)
+        self.weight_dtype = "fp8_e4m3" if _lib.DTYPES.get(weight_dtype) == _lib.DTYPE_FP8_E4M3 else "bf16"
+        ccfg = _c_config(config, weight_dtype, fp8_act_scales)
         _lib.check(self._lib.sd_unet_create(C.byref(ccfg), C.byref(self._handle)), "sd_unet_create")
         for name, shape in param_shapes(config):
             if name not in state_dict:
@@ -128,7 +137,8 @@ class HipUNet2DConditionModel:
                                              cache_mode, self.cache_branch_id), "sd_unet_forward")
         return out
 
-    KIND_NAMES = ("sinusoid", "gemv", "conv_in", "groupnorm", "conv3x3", "gemm", "layernorm", "attention", "conv_out")
+    KIND_NAMES = {0: "sinusoid", 1: "gemv", 2: "conv_in", 3: "groupnorm", 4: "conv3x3", 5: "gemm", 6: "layernorm",
+                  7: "attention", 8: "conv_out", 16: "conv3x3_fp8", 17: "gemm_fp8"}
 
     def forward_profiled(self, latents: torch.Tensor, unet_batch: int, timestep: float, cache_mode: int = CACHE_OFF):
         """One forward with a hipEvent pair around every launch (measurement only, synchronises).
@@ -137,13 +147,14 @@ class HipUNet2DConditionModel:
         out = torch.empty((unet_batch, self.config.out_channels, latents.shape[2], latents.shape[3]),
                           dtype=torch.float32, device=self.device)
         ws = self._workspace(unet_batch)
-        ms, fl, by = (C.c_double * 16)(), (C.c_double * 16)(), (C.c_double * 16)()
-        ln = (C.c_longlong * 16)()
+        ms, fl, by = (C.c_double * 32)(), (C.c_double * 32)(), (C.c_double * 32)()
+        ln = (C.c_longlong * 32)()
         _lib.check(self._lib.sd_unet_forward_profiled(
             self._handle, _lib.current_stream(), latents.data_ptr(), latents.shape[0], unet_batch, float(timestep),
             out.data_ptr(), self._ws_ptr(ws), ws.numel() - 256, cache_mode, self.cache_branch_id, ms, ln, fl, by),
             "sd_unet_forward_profiled")
-        return {n: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, n in enumerate(self.KIND_NAMES)}
+        return {n: dict(ms=ms[i], launches=ln[i], flops=fl[i], bytes=by[i]) for i, n in self.KIND_NAMES.items()
+                if ln[i] or i < 9}
 
     def __call__(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor = None,
                  timestep_cond=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict: bool = False,

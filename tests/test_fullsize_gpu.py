@@ -1,0 +1,108 @@
+"""Parity at the BENCHMARK size: SD-1.5 UNet at sample_size 64 (512x512 images), where the plan dispatches
+differently from the reduced-size tests -- `attn_pipe40_kernel` at 4096 tokens, the head-dim-80 kernel at 1024,
+the prompt cross-attention at every level, the real split-K factors, the ~2 GB arena with its lifetime-based
+re-use.  The fp32 CPU oracle needs ~2.5 s per sample-forward on the GPU box's host cores, so every case here is
+UNet batch 2 and the whole file stays under about a minute of oracle time.
+
+Reference call sites: src/models.py:210-261 (loop, UNet call, CFG, scheduler.step), deep_cache.py:24-29.
+Tolerances as tests/test_unet_gpu.py / test_pipeline_gpu.py (bf16 storage + fp32 accumulate vs fp32)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import cosine, oracle_cfg, rel_l2, synth_inputs
+
+UNET_TOL = 2e-2       # one forward, noise prediction
+STEP_TOL = 5e-3       # teacher-forced latents after one fused CFG + scheduler step of the 50-step schedule
+
+
+@pytest.fixture(scope="module")
+def full():
+    from sonicdiffusionbayeslab_amd.unet import HipUNet2DConditionModel
+    from sonicdiffusionbayeslab_amd.weights import UNetConfig, make_synthetic_state_dict
+    os.environ["SD_DEBUG_TAPS"] = "1"
+    cfg = UNetConfig(sample_size=64)
+    sd = make_synthetic_state_dict(cfg, seed=1234)
+    net = HipUNet2DConditionModel(cfg, sd)
+    os.environ.pop("SD_DEBUG_TAPS")
+    return cfg, sd, net
+
+
+@pytest.mark.parametrize("t", [981.0, 21.0])
+def test_full_size_unet_forward_matches_oracle(full, t):
+    """(a) whole-UNet forward, UNet batch 2 (one CFG pair), with the per-block tap report."""
+    from oracle.unet import unet_forward
+    cfg, sd, net = full
+    lat, pe, ne = synth_inputs(cfg, 1)
+    ctx = torch.cat([ne, pe])
+    taps = {}
+    with torch.no_grad():
+        ref = unet_forward(sd, oracle_cfg(cfg), torch.cat([lat, lat]), t, ctx, taps=taps)
+    net.set_deepcache(-1)
+    net.set_context(ctx.cuda())
+    eps = net.forward_latents(lat.cuda(), 2, t)
+    torch.cuda.synchronize()
+    report = []
+    for name, rt in taps.items():
+        got = net.debug_tensor(name, 2, rt.numel()).view(rt.shape[0], rt.shape[2], rt.shape[3], rt.shape[1])
+        report.append((name, round(rel_l2(got.permute(0, 3, 1, 2), rt), 5)))
+    err = rel_l2(eps, ref)
+    print(f"64x64 t={t}: taps {report} final {err:.3e} cos {cosine(eps, ref):.5f}")
+    assert torch.isfinite(eps).all()
+    assert err < UNET_TOL, report
+
+
+def test_full_size_two_step_ddim_teacher_forced(full):
+    """(b) the first two of 50 DDIM steps (the benchmark's schedule), CFG 7.5, 64x64: the HIP UNet + fused CFG/step
+    kernel are fed the ORACLE's latents of each step and must reproduce its noise prediction and its next latents."""
+    from oracle.pipeline import sample_loop
+    from oracle.schedulers import DDIMOracle
+    from sonicdiffusionbayeslab_amd.registry import schedulers_registry
+    from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
+    cfg, sd, net = full
+    lat, pe, ne = synth_inputs(cfg, 1, seed=31)
+    ref, _, _, traj = sample_loop(sd, oracle_cfg(cfg), DDIMOracle(), pe, ne, lat, 50, 7.5, max_steps=2)
+    s = schedulers_registry["ddim_scheduler"].from_config(PNDMConfigStub().config)
+    s.set_timesteps(50, device="cuda")
+    net.set_deepcache(-1)
+    net.set_context(torch.cat([ne, pe]).cuda())
+    x = lat
+    for k, t in enumerate(s._timesteps_list[:2]):
+        eps = net.forward_latents(x.cuda(), 2, float(t))
+        u, c = eps.float().cpu().chunk(2)
+        e_eps = rel_l2(u + 7.5 * (c - u), traj["noise_pred"][k])
+        prev, _ = s.step_fused(eps, 7.5, x.cuda(), t, cfg=True)
+        e_lat = rel_l2(prev, traj["latents"][k])
+        print(f"64x64 DDIM step {k} (t={t}): noise-pred rel-L2 {e_eps:.3e}, latents rel-L2 {e_lat:.3e}")
+        assert e_eps < 4e-2 and e_lat < STEP_TOL      # CFG amplifies the difference of two predictions 7.5x
+        x = traj["latents"][k]                         # teacher forcing
+    assert rel_l2(x, ref) == 0.0
+
+
+def test_full_size_deepcache_full_and_skip_pair(full):
+    """(c) DeepCache(interval 3, branch 0) at 64x64: one full step that stores the cache, then one skip step that
+    re-uses it (the 4096-token self-attention + 640->320 conv path of SURVEY a9)."""
+    from oracle.unet import DeepCacheState, unet_forward
+    from sonicdiffusionbayeslab_amd.unet import CACHE_FULL_AND_STORE, CACHE_SKIP
+    cfg, sd, net = full
+    lat, pe, ne = synth_inputs(cfg, 1, seed=43)
+    lat2 = lat + 0.05 * synth_inputs(cfg, 1, seed=44)[0]            # the latents a step later
+    ctx = torch.cat([ne, pe])
+    dc = DeepCacheState(cache_interval=3, cache_branch_id=0, enabled=True)
+    with torch.no_grad():
+        dc.cur_timestep = 0
+        r_full = unet_forward(sd, oracle_cfg(cfg), torch.cat([lat, lat]), 981.0, ctx, dc=dc)
+        dc.cur_timestep = 1
+        r_skip = unet_forward(sd, oracle_cfg(cfg), torch.cat([lat2, lat2]), 961.0, ctx, dc=dc)
+    net.set_deepcache(0)
+    net.set_context(ctx.cuda())
+    g_full = net.forward_latents(lat.cuda(), 2, 981.0, cache_mode=CACHE_FULL_AND_STORE).clone()
+    g_skip = net.forward_latents(lat2.cuda(), 2, 961.0, cache_mode=CACHE_SKIP).clone()
+    net.set_deepcache(-1)
+    e1, e2 = rel_l2(g_full, r_full), rel_l2(g_skip, r_skip)
+    print(f"64x64 DeepCache(3,0): full step rel-L2 {e1:.3e}, skip step rel-L2 {e2:.3e}; "
+          f"skip-vs-full prediction distance {rel_l2(r_skip, r_full):.3e}")
+    assert e1 < UNET_TOL and e2 < UNET_TOL
