@@ -69,6 +69,12 @@ int sd_unet_param_info(const sd_unet* u, int index, char* name, int name_cap, lo
 int sd_unet_load_param(sd_unet* u, const char* name, const float* host_data, long long numel);
 int sd_unet_finalize(sd_unet* u);
 
+/* Parity hook for the HOST side of sd_unet_finalize (weight repacking / fp8 quantisation): finalize packs into a host
+ * staging blob first and uploads second, so on a box without a GPU it fails at the upload with the blob intact; this
+ * copies `nbytes` of the packed item `key` (a diffusers parameter name; fp8 items: name + ".fp8" / ".scale") out of
+ * it.  Returns the item's byte offset, < 0 on error (unknown key, blob already released after a successful upload). */
+long long sd_unet_debug_packed(const sd_unet* u, const char* key, void* host_out, long long nbytes);
+
 /* Workspace the caller must provide for a given UNet batch (2*B with CFG).  `cache_branch_id`
  * < 0 disables the DeepCache plan; >= 0 reserves the cached tensors of that branch
  * (DeepCacheSDHelper.set_params, src/experiments/deep_cache.py:25-28). The SAME workspace must be

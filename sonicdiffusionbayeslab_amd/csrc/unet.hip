@@ -463,7 +463,10 @@ struct Packer {
         float* bo = (float*)(u->hblob.data() + boff);
         std::vector<float> perm(u->fp8 ? w.size() : 0);
         unsigned short* o = nullptr;
-        if (!u->fp8) o = (unsigned short*)(u->hblob.data() + alloc(t + "ff.geglu.weight", w.size() * 2));
+        if (!u->fp8) {
+            const size_t woff = alloc(t + "ff.geglu.weight", w.size() * 2);     // (alloc may move the blob: take data() after it)
+            o = (unsigned short*)(u->hblob.data() + woff);
+        }
         for (int r = 0; r < 2 * H; ++r) {
             const int grp = r / 32, within = r % 32;
             const int src = within < 16 ? grp * 16 + within : H + grp * 16 + (within - 16);
@@ -1328,14 +1331,24 @@ extern "C" int sd_unet_finalize(sd_unet* u) {
     SD_REQUIRE(u, "finalize: null handle");
     SD_REQUIRE(!u->finalized, "finalize: already finalized");
     for (auto& p : u->params) SD_REQUIRE(p.loaded, "finalize: parameter '%s' was never loaded", p.name.c_str());
+    if (pack_all(u)) return -1;          // host-only: repacks / quantises into the staging blob (runs without a GPU too)
     if (ensure_zero_page()) return -2;
-    if (pack_all(u)) return -1;
     SD_CHECK_HIP(hipMalloc((void**)&u->dweights, u->hblob.size()));
     SD_CHECK_HIP(hipMemcpy(u->dweights, u->hblob.data(), u->hblob.size(), hipMemcpyHostToDevice));
     std::vector<unsigned char>().swap(u->hblob);
     for (auto& p : u->params) std::vector<float>().swap(p.data);
     u->finalized = true;
     return 0;
+}
+
+extern "C" long long sd_unet_debug_packed(const sd_unet* u, const char* key, void* host_out, long long nbytes) {
+    SD_REQUIRE(u && key, "debug_packed: null argument");
+    auto it = u->woff.find(key);
+    SD_REQUIRE(it != u->woff.end(), "debug_packed: no packed item '%s'", key);
+    SD_REQUIRE(!u->hblob.empty(), "debug_packed: the host staging blob is released once the weights are on the device");
+    SD_REQUIRE(nbytes >= 0 && it->second + (size_t)nbytes <= u->hblob.size(), "debug_packed: '%s' + %lld bytes exceeds the blob", key, nbytes);
+    if (host_out && nbytes) memcpy(host_out, u->hblob.data() + it->second, (size_t)nbytes);
+    return (long long)it->second;
 }
 
 extern "C" long long sd_unet_workspace_bytes(sd_unet* u, int unet_batch, int cache_branch_id) {

@@ -336,3 +336,64 @@ def test_fuse_lora_state_dict_kohya_and_peft_layouts():
     assert torch.equal(sd[lin + ".weight"], r16(base[lin + ".weight"] + ul @ dl))
     with pytest.raises(KeyError):
         fuse_lora_state_dict(dict(base), {"lora_unet_no_such_module.lora_down.weight": dl}, 1.0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_finalize_packs_weights_on_the_host(dtype):
+    """sd_unet_finalize repacks (and for fp8 quantises) on the host BEFORE it touches the device, so the packer runs
+    here without a GPU: the e4m3 codes and per-output-channel scales it writes must equal the oracle's quantiser
+    (oracle/fp8.py) bit for bit, in the layouts the kernels read."""
+    from oracle.fp8 import quantize_rows
+    from sonicdiffusionbayeslab_amd.unet import _c_config
+    from sonicdiffusionbayeslab_amd.weights import make_synthetic_state_dict
+    if torch.cuda.is_available():
+        pytest.skip("host-side packer check runs on the CPU-only box (the blob is released after a successful upload)")
+    lib = _lib.load()
+    cfg = UNetConfig(sample_size=8, block_out_channels=(320, 640), attn_levels=(True, False))
+    sd = make_synthetic_state_dict(cfg, seed=5)
+    h = C.c_void_p()
+    _lib.check(lib.sd_unet_create(C.byref(_c_config(cfg, dtype)), C.byref(h)))
+    for name, shape in param_shapes(cfg):
+        t = sd[name].float().contiguous()
+        _lib.check(lib.sd_unet_load_param(h, name.encode(), t.data_ptr(), t.numel()))
+    rc = lib.sd_unet_finalize(h)
+    assert rc == -2 and b"hipMalloc" in lib.sd_last_error()           # packed, then no device to upload to
+
+    def packed(key, nbytes, dt):
+        buf = torch.empty(nbytes, dtype=torch.uint8)
+        assert lib.sd_unet_debug_packed(h, key.encode(), buf.data_ptr(), nbytes) >= 0, lib.sd_last_error()
+        return buf.view(dt)
+
+    def same_codes(a, b):                                             # +0 and -0 are the same value
+        return ((a == b) | (((a & 0x7f) == 0) & ((b & 0x7f) == 0))).all()
+
+    p = "down_blocks.1.resnets.0."                                    # 320 -> 640 channels
+    w = sd[p + "conv1.weight"]
+    if dtype == "bf16":
+        got = packed(p + "conv1.weight", w.numel() * 2, torch.bfloat16).view(640, 5, 9, 64)
+        assert torch.equal(got.float(), w.permute(0, 2, 3, 1).reshape(640, 9, 5, 64).permute(0, 2, 1, 3).bfloat16().float())
+        assert lib.sd_unet_debug_packed(h, (p + "conv1.weight.fp8").encode(), None, 0) < 0
+    else:
+        q, scale = quantize_rows(w)
+        codes = q.to(torch.float8_e4m3fn).view(torch.uint8)          # [640, 320, 3, 3]
+        want = torch.zeros(640, 384, 3, 3, dtype=torch.uint8)        # Cin 320 padded to 3 slices of 128
+        want[:, :320] = codes
+        want = want.permute(0, 2, 3, 1).reshape(640, 9, 3, 128).permute(0, 2, 1, 3).contiguous()
+        got = packed(p + "conv1.weight.fp8", 640 * 9 * 384, torch.uint8).view(640, 3, 9, 128)
+        assert same_codes(got, want)
+        assert torch.equal(packed(p + "conv1.weight.scale", 640 * 4, torch.float32), scale)
+        # GEGLU rows: interleaved [16 value | 16 gate] per 32, K = 320 padded to 384
+        t = "down_blocks.0.attentions.0.transformer_blocks.0."
+        wq, sc = quantize_rows(sd[t + "ff.net.0.proj.weight"])       # [2560, 320]
+        H = 1280
+        idx = [g * 16 + k if k < 16 else H + g * 16 + k - 16 for g in range(2 * H // 32) for k in range(32)]
+        got = packed(t + "ff.geglu.weight.fp8", 2 * H * 384, torch.uint8).view(2 * H, 384)
+        want = wq[idx].to(torch.float8_e4m3fn).view(torch.uint8)
+        assert same_codes(got[:, :320], want) and (got[:, 320:] == 0).all()
+        assert torch.equal(packed(t + "ff.geglu.weight.scale", 2 * H * 4, torch.float32), sc[idx])
+        # fused QKV rows of the self-attention
+        rows = torch.cat([sd[t + f"attn1.to_{x}.weight"] for x in "qkv"])
+        wq, sc = quantize_rows(rows)
+        got = packed(t + "attn1.qkv.weight.fp8", 960 * 384, torch.uint8).view(960, 384)
+        assert same_codes(got[:, :320], wq.to(torch.float8_e4m3fn).view(torch.uint8)) and (got[:, 320:] == 0).all()
+    lib.sd_unet_destroy(h)
