@@ -133,7 +133,8 @@ int sd_clip_encode(sd_clip* c, void* stream, const int* input_ids, int batch, fl
 
 /* Measurement hook for bench.py: the same forward with a hipEvent pair around every launch.  Per
  * op kind (0 sinusoid, 1 gemv, 2 conv_in, 3 groupnorm, 4 conv3x3, 5 gemm, 6 layernorm,
- * 7 attention, 8 conv_out; 16 conv3x3 with fp8 operands, 17 gemm with fp8 operands) it returns summed
+ * 7 attention, 8 conv_out; 16 conv3x3 with fp8 operands, 17 gemm with fp8 operands, 18 fused prompt cross-attention)
+ * it returns summed
  * milliseconds, launch count, algorithmic FLOPs and algorithmic HBM bytes in arrays of SD_PROFILE_KINDS = 32
  * entries.  Synchronises the stream; never used inside a timed region. */
 #define SD_PROFILE_KINDS 32
@@ -187,6 +188,15 @@ int sd_op_conv_out(void* stream, const void* x, const void* Wp, const float* bia
                    int Cin, int Cout);
 int sd_op_time_embedding(void* stream, float t, const void* W1, const float* b1, const void* W2, const float* b2,
                          float* scratch, float* temb, int dim_in, int dim);
+
+/* Fused prompt cross-attention of one transformer block (src/models.py:227-235 -> diffusers Attention over the 77 prompt
+ * keys): Y = R + sum_h softmax_L(X A_h) B_h + b_o in ONE launch, probabilities kept in registers.  8 heads x 80 key
+ * slots.  At [samples][640][C] bf16: row (head, slot) = scale * K_h[slot] . W_q,h (zero rows for slots >= L);
+ * Bw [samples][C][640] bf16: row = output channel, columns (head, slot) with bits 2 and 3 of the slot index swapped
+ * inside every group of 16 (the order in which an MFMA accumulator tile is consumed as the next product's operand).
+ * sd_unet_set_context builds both from the prompt.  M tokens, rows_per_sample tokens per sample (multiple of 128). */
+int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                      const float* bias, int M, int C, int rows_per_sample, int L);
 
 /* ---- fp8-e4m3 operand path (SD_DTYPE_FP8_E4M3), operator level ------------------------------------------------
  * X, W hold OCP e4m3 bytes; K / Cin count fp8 elements and are multiples of 128 (zero padded); wscale [N] fp32 is the

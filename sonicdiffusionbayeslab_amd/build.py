@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsdhip.so")
-SOURCES = ["gemm_conv.hip", "conv_halo.hip", "norm.hip", "attention.hip", "small.hip", "clip.hip", "unet.hip"]
+SOURCES = ["gemm_conv.hip", "conv_halo.hip", "norm.hip", "attention.hip", "xattn.hip", "small.hip", "clip.hip", "unet.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "sd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # attention is VALU-bound: keep MFMA results in arch VGPRs (no v_accvgpr_read/write copies)

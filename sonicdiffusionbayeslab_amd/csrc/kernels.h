@@ -99,7 +99,22 @@ int sd_launch_gemv(const float* x, const bf16_t* W, const float* b, float* y, in
                    hipStream_t stream);
 int sd_launch_timestep_sinusoid(float t, float* out, int dim, hipStream_t stream);
 int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
-int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream);
+// dst[b][c][r'] = src[b][r][c]; perm16: r' = r with bits 2 and 3 swapped (the k order in which a 32x32 MFMA
+// accumulator tile is consumed as the next product's operand, see xattn.hip)
+int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream, int perm16 = 0);
+
+// xattn.hip: fused prompt cross-attention  Y = R + sum_h softmax_L(X A_h) B_h + b_o  (one launch per block)
+struct XattnArgs {
+    const bf16_t* X = nullptr;    // [M, C] LayerNorm output
+    const bf16_t* R = nullptr;    // [M, C] residual
+    bf16_t* Y = nullptr;          // [M, C]
+    const bf16_t* At = nullptr;   // [samples][640][C]: row (head, key slot) = scale * K_h[key] . W_q,h, zero rows for slots >= L
+    const bf16_t* Bw = nullptr;   // [samples][C][640]: row = output channel, (head, key slot) contiguous in PERMUTED k order
+    const float* bias = nullptr;  // [C] to_out bias
+    int M = 0, C = 0, rows_per_sample = 0, L = 0;
+};
+bool sd_xattn_fused_applicable(int rows_per_sample, int C, int heads, int L);
+int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream);
 int sd_launch_xattn_expand(const bf16_t* kv, bf16_t* out, int B, int L, int C, int NH, int col_off, float scale,
                            hipStream_t stream);
 // clip.hip: CLIP text encoder pieces

@@ -222,7 +222,7 @@ __global__ void xattn_expand_kernel(const bf16_t* __restrict__ kv, bf16_t* __res
 }
 
 // dst[b][c][r] = src[b][r][c]  (bf16, 32x32 tiles through LDS)
-__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc) {
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc, int perm16) {
     __shared__ bf16_t tile[32][33];
     const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
@@ -232,12 +232,18 @@ __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __
         if (r0 + i < R && c0 + tx < Cc) tile[i][tx] = s[(long)(r0 + i) * Cc + c0 + tx];
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
-        if (c0 + i < Cc && r0 + tx < R) d[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+        if (c0 + i < Cc && r0 + tx < R) {
+            int rr = r0 + tx;
+            if (perm16) rr = (rr & ~12) | ((rr & 4) << 1) | ((rr & 8) >> 1);
+            d[(long)(c0 + i) * R + rr] = tile[tx][i];
+        }
 }
 
-int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream) {
+int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream, int perm16) {
     SD_REQUIRE(src && dst && B > 0 && B <= 65535 && R > 0 && Cc > 0, "transpose: B=%d R=%d C=%d", B, R, Cc);
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, B), dim3(256), 0, stream, src, dst, R, Cc);
+    SD_REQUIRE(!perm16 || R % 16 == 0, "transpose: the 16-group permutation needs R=%d to be a multiple of 16", R);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, B), dim3(256), 0, stream, src, dst, R, Cc,
+                       perm16);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -83,7 +83,7 @@ struct Wrap {  // one DeepCache-wrapped module enclosing an op
 };
 
 enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT, OP_SOFTMAX, OP_PQCONV,
-              OP_CLIP_EMBED, OP_CLIP_ATTN, OP_QGELU, OP_TO_F32 };
+              OP_CLIP_EMBED, OP_CLIP_ATTN, OP_QGELU, OP_TO_F32, OP_XATTN };
 
 struct Op {
     int kind = 0;
@@ -132,7 +132,7 @@ struct Plan {
     std::vector<int> ctx_c;               // C per layer
     int ctx_bf16 = -1;                    // bf16 copy of encoder_hidden_states
     // folded prompt cross-attention (per layer): A^T [UB][heads*80][C] and B [UB][C][heads*80], see transformer()
-    struct Fold { int kv, at, bw, C; size_t wqT, wo; };
+    struct Fold { int kv, at, bw, C; size_t wqT, wo; bool perm; };   // perm: Bw in the fused kernel's k order
     std::vector<Fold> ctx_fold;
     int ctx_fold_scratch = -1;            // masked K / V expansions [2][UB][heads*80][Cmax]
     std::map<std::string, int> taps;
@@ -782,18 +782,26 @@ struct Builder {
         pl.ctx_w.push_back(W(t + "attn2.kv.weight"));
         pl.ctx_c.push_back(C);
         int h2;
-        // SD_XATTN_FOLD: 0 = never, n > 0 = levels with at most n tokens.  Default 1024 (the 32x32 and 16x16 levels):
-        // measured +0.6 % images/s; at 64x64 the P tensor (M x 640) costs as much HBM traffic as Q and O did.
+        // Prompt cross-attention.  The prompt is step-invariant, so per sample and head
+        //   A_h = scale * W_q,h^T K_h^T  [C x 77]   and   B_h = V_h W_o,h^T  [77 x C]
+        // are computed once per sampling run (sd_unet_set_context; 80 key slots per head, 3 of them padding).
+        //  * SD_XATTN_FUSED (levels with >= n tokens, default 1024 = 64x64 and 32x32; 0 = never): ONE launch,
+        //    Y = h1 + sum_h softmax_77(X A_h) B_h + b_o with the probabilities kept in registers (xattn.hip);
+        //  * SD_XATTN_FOLD (levels with <= n tokens, default 1024): two GEMMs with per-sample weights,
+        //    P = softmax_77(X A) in the GEMM epilogue and h2 = h1 + P B + b_o;
+        //  * otherwise to_q GEMM, the 77-key flash-attention kernel and the to_out GEMM.
+        static const int fused_min_hw = getenv("SD_XATTN_FUSED") ? atoi(getenv("SD_XATTN_FUSED")) : 1024;
         static const int fold_max_hw = getenv("SD_XATTN_FOLD") ? atoi(getenv("SD_XATTN_FOLD")) : 1024;
-        if (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) {
-            // Folded prompt cross-attention.  The prompt is step-invariant, so per sample and head
-            //   A_h = scale * W_q,h^T K_h^T  [C x 77]   and   B_h = V_h W_o,h^T  [77 x C]
-            // are computed once per sampling run (sd_unet_set_context) and every step is two GEMMs with per-sample
-            // weights,  P = softmax_77(X A)  (80 columns per head, 3 of them padding)  and  h2 = h1 + P B + b_o:
-            // to_q, the 77-key attention kernel and to_out, with their Q / O round trips through HBM, are gone.
-            const int NH = u->cfg.num_heads, NP = NH * 80;
+        const int NH = u->cfg.num_heads, NP = NH * 80;
+        if (fused_min_hw > 0 && hw >= fused_min_hw && sd_xattn_fused_applicable(hw, C, NH, L)) {
             int at = tensor((size_t)UB * NP * C * 2, true), bw = tensor((size_t)UB * C * NP * 2, true);
-            pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight")});
+            pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight"), true});
+            Op o; o.kind = OP_XATTN; o.x1 = n2; o.r = h1; o.wt = at; o.x2 = bw; o.M = M; o.N = C; o.K = NP; o.rpb = hw;
+            o.sm_valid = L; o.b = W(t + "attn2.to_out.0.bias"); o.heads = NH;
+            o.out = tensor((size_t)M * C * 2); push(o); h2 = o.out;
+        } else if (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) {
+            int at = tensor((size_t)UB * NP * C * 2, true), bw = tensor((size_t)UB * C * NP * 2, true);
+            pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight"), false});
             int pr;
             { Op o; o.kind = OP_GEMM; o.x1 = n2; o.K1 = C; o.K = C; o.M = M; o.N = NP; o.epi = 2; o.sm_valid = L;
               o.wt = at; o.wbs = (long)NP * C; o.rpb = hw; o.out = tensor((size_t)M * NP * 2); push(o); pr = o.out; }
@@ -1168,6 +1176,13 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.consts = g_zero_page;
             return sd_launch_attention(a, stream);
         }
+        case OP_XATTN: {
+            XattnArgs a;
+            a.X = (const bf16_t*)T(o.x1); a.R = (const bf16_t*)T(o.r); a.Y = (bf16_t*)T(o.out);
+            a.At = (const bf16_t*)T(o.wt); a.Bw = (const bf16_t*)T(o.x2); a.bias = (const float*)(wb + o.b);
+            a.M = o.M; a.C = o.N; a.rows_per_sample = o.rpb; a.L = o.sm_valid;
+            return sd_launch_xattn_fused(a, stream);
+        }
         case OP_CLIP_EMBED:
             return sd_launch_clip_embed((const int*)latents, (const bf16_t*)(wb + o.w), (const bf16_t*)(wb + o.g),
                                         (bf16_t*)T(o.out), o.M, o.Nk, o.N, u->clip.vocab_size, stream);
@@ -1404,7 +1419,8 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
             a.C = kexp; a.ldc = C;
             a.zero_page = g_zero_page;
             if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
-            if ((rc = sd_launch_transpose_bf16(kexp, (bf16_t*)(ws + pl.tensors[f.bw].off), unet_batch, NP, C, (hipStream_t)stream)))
+            if ((rc = sd_launch_transpose_bf16(kexp, (bf16_t*)(ws + pl.tensors[f.bw].off), unet_batch, NP, C, (hipStream_t)stream,
+                                               f.perm ? 1 : 0)))
                 return rc;
         }
     }
@@ -1445,6 +1461,10 @@ static void op_work(const Op& o, double* flops, double* bytes) {
             *bytes = esz * ((double)o.M * K + (double)o.N * K) + (o.out_fp8 ? 1.0 : 2.0) * (double)o.M * (o.epi == 1 ? o.N / 2 : o.N);
             break;
         }
+        case OP_XATTN:   // to_q + Q K^T + P V + to_out of the block (to_k / to_v are hoisted out of the loop); X, R in, Y out
+            *flops = 4.0 * o.M * (double)o.N * o.N + 4.0 * o.M * (double)o.sm_valid * o.N;
+            *bytes = 3.0 * 2.0 * o.M * o.N;
+            break;
         case OP_ATTN:
             *flops = 4.0 * o.B * o.heads * (double)o.Nq * o.Nk * o.D;
             *bytes = 2.0 * o.B * o.heads * o.D * (2.0 * o.Nq + 2.0 * o.Nk);
@@ -1494,7 +1514,7 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
         const Op& o = pl->ops[which[j]];
         double fl, by;
         op_work(o, &fl, &by);
-        const int kd = o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind;
+        const int kd = o.kind == OP_XATTN ? 18 : (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
         kind_ms[kd] += ms; kind_launches[kd] += 1; kind_flops[kd] += fl; kind_bytes[kd] += by;
     }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -1680,4 +1700,15 @@ extern "C" int sd_op_layernorm_fp8(void* stream, const void* x, const float* gam
 
 extern "C" int sd_op_quantize_fp8(void* stream, const void* x_bf16, void* y_fp8, long long rows, int C, int Cpad, float scale) {
     return sd_launch_quantize_fp8((const bf16_t*)x_bf16, y_fp8, (long)rows, C, Cpad, scale, (hipStream_t)stream);
+}
+
+// ---- fused prompt cross-attention, operator level: Y = R + sum_h softmax_L(X A_h) B_h + b_o (xattn.hip) ----
+extern "C" int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                                 const float* bias, int M, int C, int rows_per_sample, int L) {
+    SD_REQUIRE(sd_xattn_fused_applicable(rows_per_sample, C, 8, L) || getenv("SD_XATTN_FUSED"),
+               "sd_op_xattn_fused: shape not supported (8 heads x 80 key slots, 64 < L <= 80, C %% 32 == 0, tokens per sample %% 128 == 0)");
+    XattnArgs a;
+    a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
+    a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L;
+    return sd_launch_xattn_fused(a, (hipStream_t)stream);
 }

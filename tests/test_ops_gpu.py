@@ -312,3 +312,57 @@ def test_gemm_batched_weights_and_grouped_softmax(sdlib, B, rows, N, K, epi):
     if epi == 2:
         o = out.float().view(B * rows, N // 80, 80)
         assert (o[..., 77:] == 0).all() and (o.sum(-1) - 1).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("B,hw,C,spike", [(2, 256, 320, False), (1, 1024, 640, True), (3, 128, 1280, False), (2, 4096, 320, False)])
+def test_xattn_fused(sdlib, B, hw, C, spike):
+    """Fused prompt cross-attention (xattn.hip; src/models.py:227-235 -> diffusers Attention over the 77 prompt keys):
+    Y = R + to_out(softmax(to_q(X) K^T / sqrt(d)) V) + b in ONE launch with A_h = scale W_q,h^T K_h^T and
+    B_h = V_h W_o,h^T precomputed per prompt.  Checked against (i) the same folded form evaluated in fp32 from the
+    bf16-rounded A / B (kernel arithmetic: probabilities are rounded to bf16 before the second product -> 8e-3) and
+    (ii) F.scaled_dot_product_attention + linears on the unfolded weights (the formulation itself, incl. the
+    bf16 rounding of A and B: 2e-2)."""
+    g = torch.Generator().manual_seed(B * 1000 + hw + C)
+    H, L, d = 8, 77, C // 8
+    M = B * hw
+    x = r16(torch.randn(M, C, generator=g))
+    r = r16(torch.randn(M, C, generator=g))
+    wq, wo = (torch.randn(C, C, generator=g) / math.sqrt(C) for _ in range(2))
+    wk, wv = (torch.randn(C, 768, generator=g) / math.sqrt(768) for _ in range(2))
+    bo = torch.randn(C, generator=g)
+    ctx = torch.randn(B, L, 768, generator=g)
+    if spike:
+        ctx[0, 5] *= 6.0                      # one dominant key: exercises the max subtraction
+    K, V = ctx @ wk.t(), ctx @ wv.t()         # [B, L, C]
+    scale = 1.0 / math.sqrt(d)
+    At = torch.zeros(B, H * 80, C)
+    Bn = torch.zeros(B, H * 80, C)            # natural key order, [key slot][channel]
+    for hh in range(H):
+        sl = slice(hh * d, (hh + 1) * d)
+        At[:, hh * 80: hh * 80 + L] = scale * K[:, :, sl] @ wq[sl, :]
+        Bn[:, hh * 80: hh * 80 + L] = V[:, :, sl] @ wo[:, sl].t()
+    At, Bn = r16(At), r16(Bn)
+    # (i) folded reference from the rounded operands
+    xs = x.view(B, hw, C)
+    S = torch.einsum("bmc,bkc->bmk", xs, At).view(B, hw, H, 80)
+    S[..., L:] = float("-inf")
+    Pm = torch.softmax(S, dim=-1).view(B, hw, H * 80)
+    ref_fold = (r.view(B, hw, C) + torch.einsum("bmk,bkc->bmc", Pm, Bn) + bo).view(M, C)
+    # (ii) the unfolded attention
+    q = (xs @ wq.t()).view(B, hw, H, d).transpose(1, 2)
+    kk, vv = (t.view(B, L, H, d).transpose(1, 2) for t in (K, V))
+    o = F.scaled_dot_product_attention(q, kk, vv).transpose(1, 2).reshape(B, hw, C)
+    ref_attn = (r.view(B, hw, C) + o @ wo.t() + bo).view(M, C)
+    # Bw: [B][C][640] with bits 2 and 3 of the key slot swapped inside every group of 16
+    slot = torch.arange(H * 80)
+    perm = (slot & ~12) | ((slot & 4) << 1) | ((slot & 8) >> 1)
+    Bw = torch.zeros(B, C, H * 80)
+    Bw[:, :, perm] = Bn.transpose(1, 2)
+    out = torch.full((M, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_xattn_fused(stream(), P(x, torch.bfloat16), P(r, torch.bfloat16), P(out), P(At, torch.bfloat16),
+                                       P(Bw.contiguous(), torch.bfloat16), P(bo), M, C, hw, L))
+    torch.cuda.synchronize()
+    e1, e2 = rel_l2(out, ref_fold), rel_l2(out, ref_attn)
+    print(f"xattn fused B={B} hw={hw} C={C}: vs folded fp32 {e1:.3e}, vs SDPA + linears {e2:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert e1 < 8e-3 and e2 < 2e-2
