@@ -1,0 +1,38 @@
+"""Per-kernel summary of a `rocprofv3 --kernel-trace --pmc ...` pass over tools/forward_once.py (second forward only:
+the first one also pays first-touch costs).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the
+dispatch), shader cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs; MI355X_MICROARCH.md 'DVFS give-back')."""
+import collections, csv, glob, json, re, sys
+
+d, out = sys.argv[1], sys.argv[2]
+rows = []
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+disp = collections.OrderedDict()
+for r in rows:
+    k = int(r["Dispatch_Id"])
+    e = disp.setdefault(k, {"name": r["Kernel_Name"], "c": {}})
+    e["c"][r["Counter_Name"]] = e["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+ids = sorted(disp)
+half = ids[len(ids) // 2:] if len(ids) > 1 else ids          # the second forward (set_context launches sit in the first half)
+agg = collections.OrderedDict()
+for i in half:
+    e = disp[i]
+    name = re.sub(r"\(.*", "", e["name"])
+    name = re.sub(r"^void ", "", name)
+    a = agg.setdefault(name, {"launches": 0, "c": collections.defaultdict(float)})
+    a["launches"] += 1
+    for k, v in e["c"].items():
+        a["c"][k] += v
+res = {}
+for name, a in agg.items():
+    c = a["c"]
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    res[name] = {"launches": a["launches"], **{k: v / a["launches"] for k, v in c.items()},
+                 "shader_cycles_per_launch": cyc / a["launches"],
+                 "mfma_busy_frac": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc)) if cyc else None,
+                 "lds_conflict_frac": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None}
+json.dump(res, open(out, "w"), indent=1)
+for name, v in sorted(res.items(), key=lambda kv: -(kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES") or 0) * kv[1]["launches"]):
+    mb = v["mfma_busy_frac"]
+    print(f"{name[:70]:70s} n={v['launches']:3d} mfma_busy={mb if mb is None else round(mb, 3)} "
+          f"valu_insts={v.get('SQ_INSTS_VALU', 0):.3g} lds_conf={v['lds_conflict_frac']}")
