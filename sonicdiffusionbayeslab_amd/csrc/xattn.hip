@@ -18,8 +18,14 @@
 //             slots >= L are masked; probabilities are normalised and packed to bf16 IN PLACE -- a 32x32 accumulator
 //             tile is directly the B operand of the next product (k order inside a 16-step: 8(j>>2) + 4h + (j&3)).
 //   phase 2   Y^T[32 channels, 32 tokens] = Bw . P^T         per 32-channel tile: 40 MFMAs over the 640 key slots, Bw
-//             rows (channel-major, key-contiguous, stored in the permuted k order above) by LDS-DMA, ring of 3;
-//             epilogue: + b_o + R in fp32, bf16, v_permlane32_swap pairs the lane halves into 16-byte row stores.
+//             rows (channel-major, key-contiguous, stored in the permuted k order above) and the residual tile by
+//             LDS-DMA, ring of 3; epilogue from LDS only: + b_o + R in fp32, bf16, v_permlane32_swap pairs the lane
+//             halves into 16-byte row stores.  grid.y splits the channel tiles when the token grid alone cannot fill
+//             the chip (each slice repeats phase 1).
+// With one wave per SIMD nothing hides a wave's issue stalls, so (a) every LDS-DMA piece (~60-100 issue cycles) is
+// placed singly between two MFMAs instead of in a burst after the barrier, (b) the fragments of the next k-step are
+// requested a few MFMAs into the current one, and (c) the loops contain no ordinary global load (hipcc would drain
+// the whole DMA pipeline with vmcnt(0) at its first use): residual and bias come through LDS.
 // LDS rows are 64 B; the four 16-byte chunks of a row are XOR-swizzled by (row >> 2) & 3 on the DMA source address, which
 // makes the ds_read_b128 fragment reads (32 consecutive rows, one chunk) bank-conflict free.
 #include "common.h"
@@ -34,13 +40,16 @@ constexpr int KEYS = 640;                   // 8 heads x 80 key slots
 constexpr int HKEYS = KEYS / 2;             // key slots of one pass (4 heads)
 constexpr int NKT = HKEYS / 32;             // 10 key tiles of 32 per pass
 constexpr int STAGE1 = (HKEYS + TOK) * 64;  // 28 KiB: A^T half tile + X tile of one 32-channel K tile
-constexpr int STAGE2 = 32 * KEYS * 2;       // 40 KiB: Bw rows of one 32-channel tile
+constexpr int BWBYTES = 32 * KEYS * 2;      // 40 KiB: Bw rows of one 32-channel tile
+constexpr int STAGE2 = BWBYTES + TOK * 64;  // + the residual tile (128 tokens x 32 channels) = 48 KiB
 constexpr int NSTAGE1 = 4;                  // phase 1: two K tiles of lead
 constexpr int NSTAGE2 = 3;
-constexpr int SMEM = NSTAGE2 * STAGE2;      // 120 KiB (>= NSTAGE1 * STAGE1 = 112 KiB)
-static_assert(NSTAGE1 * STAGE1 <= SMEM, "phase-1 ring must fit the phase-2 ring");
+constexpr int RING = NSTAGE2 * STAGE2;      // 144 KiB (>= NSTAGE1 * STAGE1 = 112 KiB)
+constexpr int MAXC = 1280;
+constexpr int SMEM = RING + MAXC * 4;       // + the to_out bias
+static_assert(NSTAGE1 * STAGE1 <= RING && SMEM <= 160 * 1024, "LDS budget");
 constexpr int P1_PIECES = 7;                // 1-KiB DMA pieces per wave and K tile (28 / 4)
-constexpr int P2_PIECES = 10;               // ... per wave and channel tile (40 / 4)
+constexpr int P2_PIECES = 12;               // ... per wave and channel tile (40 + 8) / 4
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -58,40 +67,49 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
     const char* At = (const char*)p.At + (long)sample * KEYS * C * 2;
     const char* Bw = (const char*)p.Bw + (long)sample * C * KEYS * 2;
     const long rowbytes = (long)C * 2;
+    const int KT = C / 32;
+    const int NTall = C / 32, nsl = gridDim.y;
+    const int jbeg = (int)((long)NTall * blockIdx.y / nsl), NT = (int)((long)NTall * (blockIdx.y + 1) / nsl) - jbeg;
+
+    // to_out bias -> LDS (before any DMA is in flight: these are the kernel's only ordinary global loads)
+    float* sbias = (float*)(smem + RING);
+    for (int i = tid; i < C; i += 256) sbias[i] = p.bias[i];
 
     // ---- LDS-DMA source pointers (16 rows x 64 B per piece; lane -> row lane >> 2, chunk lane & 3, swizzled) ----
     const int prow = lane >> 2;
     const int sch = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;              // source chunk byte offset
-    const char* aptr = At + (long)(16 * wave + prow) * rowbytes + sch;   // piece i: + i * 64 rows; pass g: + 320 rows
-    const char* xptr = (const char*)p.X + (m0 + 16 * wave + prow) * rowbytes + sch;   // pieces 5, 6: + 64 rows
-    auto issue1 = [&](int pass, int kt, char* st) {
-        const char* ap = aptr + (long)pass * HKEYS * rowbytes + kt * 64;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) glds16(ap + (long)i * 64 * rowbytes, st + (wave + 4 * i) * 1024);
-        glds16(xptr + kt * 64, st + (20 + wave) * 1024);
-        glds16(xptr + 64 * rowbytes + kt * 64, st + (24 + wave) * 1024);
+    const char* aptr = At + (long)(16 * wave + prow) * rowbytes + sch;   // A piece i: + i * 64 rows; pass g: + 320 rows
+    const char* xptr = (const char*)p.X + (m0 + 16 * wave + prow) * rowbytes + sch;   // X piece i: + i * 64 rows
+    auto piece1 = [&](int pass, int kt, int i, char* st) {             // i = 0..4: A^T rows, 5..6: X rows
+        if (i < 5) glds16(aptr + ((long)pass * HKEYS + i * 64) * rowbytes + kt * 64, st + (wave + 4 * i) * 1024);
+        else glds16(xptr + (long)(i - 5) * 64 * rowbytes + kt * 64, st + (20 + 4 * (i - 5) + wave) * 1024);
     };
-    // phase 2: piece q = wave + 4 i covers sub-tile kt = q >> 1 (32 key slots = 64 B), rows 16 (q & 1) .. + 15
-    const char* bptr = Bw + (long)(16 * (wave & 1) + prow) * (KEYS * 2) + (wave >> 1) * 64 + sch;   // piece i: + 128 B
-    auto issue2 = [&](int j, char* st) {
-        const char* src = bptr + (long)j * 32 * (KEYS * 2);
+    auto issue1 = [&](int pass, int kt, char* st) {
 #pragma unroll
-        for (int i = 0; i < P2_PIECES; ++i) glds16(src + i * 128, st + (wave + 4 * i) * 1024);
+        for (int i = 0; i < P1_PIECES; ++i) piece1(pass, kt, i, st);
+    };
+    // phase 2: Bw piece q = wave + 4 i (i < 10) covers sub-tile kt = q >> 1 (32 key slots = 64 B), rows 16 (q & 1) .. + 15;
+    // pieces 10, 11: residual rows 16 (wave + 4 (i - 10)) .. + 15 of the token tile
+    const char* bptr = Bw + (long)(16 * (wave & 1) + prow) * (KEYS * 2) + (wave >> 1) * 64 + sch;   // piece i: + 128 B
+    const char* rptr = (const char*)p.R + (m0 + 16 * wave + prow) * rowbytes + sch;                  // piece i: + 64 rows
+    auto piece2 = [&](int j, int i, char* st) {
+        if (i < 10) glds16(bptr + (long)j * 32 * (KEYS * 2) + i * 128, st + (wave + 4 * i) * 1024);
+        else glds16(rptr + (long)(i - 10) * 64 * rowbytes + j * 64, st + BWBYTES + (wave + 4 * (i - 10)) * 1024);
+    };
+    auto issue2 = [&](int j, char* st) {
+#pragma unroll
+        for (int i = 0; i < P2_PIECES; ++i) piece2(j, i, st);
     };
 
     // ---- fragment read offsets: row r of a 32-row tile, k-step ks: chunk (2 ks + h) ^ ((r >> 2) & 3) ----
-    const int fo0 = r * 64 + (((0 + h) ^ ((r >> 2) & 3)) << 4);
-    const int fo1 = r * 64 + (((2 + h) ^ ((r >> 2) & 3)) << 4);
+    const int fsw = (r >> 2) & 3;
+    const int fo0 = r * 64 + (((0 + h) ^ fsw) << 4);
+    const int fo1 = r * 64 + (((2 + h) ^ fsw) << 4);
     const int xrow = (HKEYS + 32 * wave) * 64;
 
-    const int KT = C / 32, NT = C / 32;
     bf16x8 P[4 * NKT];              // P^T fragments of all 40 half-tiles (16 key slots each)
     const float c = 1.4426950408889634f;
 
-    // Fragment prefetch: the LDS reads of k-step 1 are issued before the MFMAs of k-step 0, and those of the NEXT
-    // tile's k-step 0 before the MFMAs of k-step 1, so that with one wave per SIMD no MFMA waits for an LDS read issued
-    // just before it.  The one barrier per K tile sits BETWEEN the two k-steps: by then every wave has left tile kt-1
-    // (its stage is refilled right after the barrier) and has retired its own DMA of tile kt+1 (read after the barrier).
     auto frags = [&](const char* sb, int fo, bf16x8* af, bf16x8& xf) {
         xf = *(const bf16x8*)(sb + xrow + fo);
 #pragma unroll
@@ -102,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
         if (KT > 1) issue1(pass, 1, smem + STAGE1);
         if (KT > 2) issue1(pass, 2, smem + 2 * STAGE1);
     };
+    __builtin_amdgcn_s_waitcnt(0);          // bias loads + LDS writes retired
     prologue1(0);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -122,8 +141,8 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
         frags(smem, fo0, a0, x0);
         for (int kt = 0; kt < KT; ++kt) {
             const char* sb = smem + (kt & 3) * STAGE1;
-            // hipcc drains lgkmcnt at a loop head; with the k-step-1 reads issued AFTER the first MFMAs that wait only
-            // covers the k-step-0 fragments requested 10 MFMAs earlier
+            // hipcc drains lgkmcnt at a loop head / block entry; with the next fragments requested AFTER the first
+            // MFMAs that wait only covers reads issued 10 MFMAs earlier
 #pragma unroll
             for (int t = 0; t < NKT; ++t) {
                 S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[t], x0, S[t], 0, 0, 0);
@@ -135,25 +154,25 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            // The one barrier per K tile sits BETWEEN the two k-steps: by then every wave has left tile kt-1 (its
+            // stage is refilled after the barrier) and has retired its own DMA of tile kt+1 (read after the barrier).
             if (kt + 1 < KT) {
                 if (kt + 2 < KT) wait_vmcnt<P1_PIECES>();   // own pieces of tile kt+1 landed, tile kt+2 may be in flight
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + 3 < KT) issue1(pass, kt + 3, smem + ((kt + 3) & 3) * STAGE1);   // the stage tile kt-1 was read from
-                __builtin_amdgcn_sched_barrier(0);
             }
+            char* refill = smem + ((kt + 3) & 3) * STAGE1;   // the stage tile kt-1 was read from
+            const bool more = kt + 3 < KT;
 #pragma unroll
             for (int t = 0; t < NKT; ++t) {
                 S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], x1, S[t], 0, 0, 0);
                 asm("" : "+a"(S[t]));
-                if (t == 1) {                           // (same reason: the block-entry wait must not cover fresh reads)
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kt + 1 < KT) frags(smem + ((kt + 1) & 3) * STAGE1, fo0, a0, x0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 1 && kt + 1 < KT) frags(smem + ((kt + 1) & 3) * STAGE1, fo0, a0, x0);
+                if (t >= 2 && t < 2 + P1_PIECES && more) piece1(pass, kt + 3, t - 2, refill);   // one DMA piece per MFMA gap
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         // every wave is done reading this pass's stages -> the next operand stream starts under the softmax
         __builtin_amdgcn_s_barrier();
@@ -161,10 +180,9 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
         if (pass == 0) {
             prologue1(1);
         } else {
-            issue2(0, smem);
-            if (NT > 1) issue2(1, smem + STAGE2);
+            issue2(jbeg, smem);
+            if (NT > 1) issue2(jbeg + 1, smem + STAGE2);
         }
-
         // =============================== softmax over each head's 80 key slots ===============================
         // lane (token r, half h) holds key 32 t + (i & 3) + 8 (i >> 2) + 4 h in S[t][i]; head hd = half-tiles 5 hd .. 5 hd + 4
         // (a half-tile = registers 8 s .. 8 s + 7 of tile t, u = 2 t + s); key slots >= L of a head sit in its last half-tile.
@@ -206,49 +224,52 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
 
     // =============================== phase 2: Y^T = Bw . P^T, 32 channels at a time ===============================
     const long trow = m0 + 32 * wave + r;                       // this lane's token
-    const char* Rrow = (const char*)p.R + trow * rowbytes;
     char* Yrow = (char*)p.Y + trow * rowbytes;
-    // Same structure: 8-deep ring of Bw fragments, the barrier of tile j+1 between MFMA 20 and 21 of tile j, the first
-    // fragments of tile j+1 requested before the epilogue of tile j.
+    // residual tile in LDS: row 32 wave + r, 16-byte chunk g (channels 8 g .. 8 g + 7) at position g ^ swizzle, + 8 h
+    const int roff = BWBYTES + (32 * wave + r) * 64 + 8 * h;
+    // 8-deep ring of Bw fragments; the barrier of tile j+1 between MFMA 20 and 21 of tile j, one DMA piece of tile j+2
+    // per MFMA gap after it, the first fragments of tile j+1 requested before the epilogue of tile j.
     auto bfrag = [&](const char* sb, int g) { return *(const bf16x8*)(sb + (g >> 1) * 2048 + ((g & 1) ? fo1 : fo0)); };
-    constexpr int RING = 8, NG = 4 * NKT;
-    bf16x8 bq[RING];
-    wait_vmcnt<0>();                                    // Bw tiles 0 and 1 (issued before the softmax)
+    constexpr int NRING = 8, NG = 4 * NKT;
+    bf16x8 bq[NRING];
+    wait_vmcnt<0>();                                    // Bw / R tiles 0 and 1 (issued before the softmax)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int g = 0; g < RING; ++g) bq[g] = bfrag(smem, g);
+    for (int g = 0; g < NRING; ++g) bq[g] = bfrag(smem, g);
     int st = 0;
-    for (int j = 0; j < NT; ++j) {
+    for (int jj = 0; jj < NT; ++jj) {
+        const int j = jbeg + jj;
         const char* sb = smem + st * STAGE2;
         const int sn = st == 2 ? 0 : st + 1;
+        char* refill = smem + (st == 0 ? 2 : st - 1) * STAGE2;
+        const bool more = jj + 2 < NT;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g == NG / 2 && j + 1 < NT) {
-                // Own DMA of tile j+1 is older than the residual / bias loads of the previous tile, whose data has been
-                // consumed; only that tile's two stores may still be in flight.
-                if (j == 0) wait_vmcnt<0>();
+            if (g == NG / 2 && jj + 1 < NT) {
+                // Own DMA of tile j+1 is older than the previous tile's two stores, the only younger vector-memory ops.
+                if (jj == 0) wait_vmcnt<0>();
                 else wait_vmcnt<2>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (j + 2 < NT) issue2(j + 2, smem + (st == 0 ? 2 : st - 1) * STAGE2);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g % RING], P[g], acc, 0, 0, 0);
-            if (g + RING < NG) bq[g % RING] = bfrag(sb, g + RING);
-            else if (j + 1 < NT) bq[g % RING] = bfrag(smem + sn * STAGE2, g + RING - NG);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g % NRING], P[g], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + NRING < NG) bq[g % NRING] = bfrag(sb, g + NRING);
+            else if (jj + 1 < NT) bq[g % NRING] = bfrag(smem + sn * STAGE2, g + NRING - NG);
+            if (g > NG / 2 && g <= NG / 2 + P2_PIECES && more) piece2(j + 2, g - NG / 2 - 1, refill);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        st = sn;
-        // ---- epilogue: lane holds channels 32 j + 8 g + 4 h + (0..3), g = 0..3, of its token ----
+        // ---- epilogue (LDS operands only): lane holds channels 32 j + 8 g + 4 h + (0..3), g = 0..3, of its token ----
         const int cb = 32 * j + 4 * h;
         u32x2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const u32x2 rr = *(const u32x2*)(Rrow + (cb + 8 * g) * 2);
-            const f32x4 bv = *(const f32x4*)(p.bias + cb + 8 * g);
+            const u32x2 rr = *(const u32x2*)(sb + roff + ((g ^ fsw) << 4));
+            const f32x4 bv = *(const f32x4*)(sbias + cb + 8 * g);
             const float y0 = acc[4 * g + 0] + bv[0] + bflo(rr[0]), y1 = acc[4 * g + 1] + bv[1] + bfhi(rr[0]);
             const float y2 = acc[4 * g + 2] + bv[2] + bflo(rr[1]), y3 = acc[4 * g + 3] + bv[3] + bfhi(rr[1]);
             pk[g] = u32x2{pack2bf(y0, y1), pack2bf(y2, y3)};
@@ -262,6 +283,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
             const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
             *(u32x4*)(Yrow + (32 * j + 16 * q + 8 * h) * 2) = o;
         }
+        st = sn;
     }
 }
 
@@ -270,12 +292,12 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
 bool sd_xattn_fused_applicable(int rows_per_sample, int C, int heads, int L) {
     static const char* env = getenv("SD_XATTN_FUSED");
     if (env && atoi(env) == 0) return false;
-    return heads == 8 && L > 64 && L <= 80 && C % 32 == 0 && C >= 64 && rows_per_sample % TOK == 0;
+    return heads == 8 && L > 64 && L <= 80 && C % 32 == 0 && C >= 64 && C <= MAXC && rows_per_sample % TOK == 0;
 }
 
 int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
     SD_REQUIRE(a.X && a.R && a.Y && a.At && a.Bw && a.bias, "xattn: null operand");
-    SD_REQUIRE(a.C % 32 == 0 && a.C >= 64, "xattn: C=%d must be a multiple of 32", a.C);
+    SD_REQUIRE(a.C % 32 == 0 && a.C >= 64 && a.C <= MAXC, "xattn: C=%d must be a multiple of 32 in [64, %d]", a.C, MAXC);
     SD_REQUIRE(a.rows_per_sample % TOK == 0 && a.M % a.rows_per_sample == 0 && a.M > 0,
                "xattn: %d tokens per sample must be a multiple of %d (M=%d)", a.rows_per_sample, TOK, a.M);
     SD_REQUIRE(a.L > 64 && a.L <= 80, "xattn: %d prompt keys (65..80 are built)", a.L);
@@ -285,7 +307,14 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    hipLaunchKernelGGL(xattn_fused_kernel, dim3(a.M / TOK), dim3(256), SMEM, stream, a);
+    // channel slices (each repeats phase 1): only when the token grid leaves most of the 256 CUs idle
+    const int wgs = a.M / TOK, nt = a.C / 32;
+    int nsl = 1;
+    static const int force = getenv("SD_XATTN_SLICES") ? atoi(getenv("SD_XATTN_SLICES")) : 0;
+    if (force > 0) nsl = force;
+    else if (wgs <= 128) nsl = 2;
+    if (nsl > nt) nsl = nt;
+    hipLaunchKernelGGL(xattn_fused_kernel, dim3(wgs, nsl), dim3(256), SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -13,11 +13,12 @@ for r in rows:
     e = disp.setdefault(k, {"name": r["Kernel_Name"], "c": {}})
     e["c"][r["Counter_Name"]] = e["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(disp)
-half = ids[len(ids) // 2:] if len(ids) > 1 else ids          # the second forward (set_context launches sit in the first half)
+starts = [i for i in ids if "sinusoid_kernel" in disp[i]["name"]]   # first launch of every forward
+half = [i for i in ids if i >= starts[-1]] if starts else ids       # the LAST forward only
 agg = collections.OrderedDict()
 for i in half:
     e = disp[i]
-    name = re.sub(r"\(.*", "", e["name"])
+    name = re.sub(r"\([^()]*\)$", "", e["name"]).replace("(anonymous namespace)::", "")
     name = re.sub(r"^void ", "", name)
     a = agg.setdefault(name, {"launches": 0, "c": collections.defaultdict(float)})
     a["launches"] += 1
@@ -32,7 +33,17 @@ for name, a in agg.items():
                  "mfma_busy_frac": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc)) if cyc else None,
                  "lds_conflict_frac": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None}
 json.dump(res, open(out, "w"), indent=1)
+import os
+times = {}
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        times[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+for name, a in agg.items():
+    ds = [times[i] for i in half if i in times and re.sub(r"^void ", "", re.sub(r"\([^()]*\)$", "", disp[i]["name"]).replace("(anonymous namespace)::", "")) == name]
+    if ds:
+        res[name]["avg_us_profiled"] = sum(ds) / len(ds)
+json.dump(res, open(out, "w"), indent=1)
 for name, v in sorted(res.items(), key=lambda kv: -(kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES") or 0) * kv[1]["launches"]):
     mb = v["mfma_busy_frac"]
-    print(f"{name[:70]:70s} n={v['launches']:3d} mfma_busy={mb if mb is None else round(mb, 3)} "
+    print(f"{name[:70]:70s} n={v['launches']:3d} us={v.get('avg_us_profiled', 0):8.1f} mfma_busy={mb if mb is None else round(mb, 3)} "
           f"valu_insts={v.get('SQ_INSTS_VALU', 0):.3g} lds_conf={v['lds_conflict_frac']}")
