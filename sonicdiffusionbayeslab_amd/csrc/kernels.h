@@ -112,6 +112,7 @@ struct XattnArgs {
     const bf16_t* Bw = nullptr;   // [samples][C][640]: row = output channel, (head, key slot) contiguous in PERMUTED k order
     const float* bias = nullptr;  // [C] to_out bias
     int M = 0, C = 0, rows_per_sample = 0, L = 0;
+    unsigned long long* stamps = nullptr;   // diagnostic: 8 s_memtime stamps per workgroup (SD_XATTN_STAMPS), else null
 };
 bool sd_xattn_fused_applicable(int rows_per_sample, int C, int heads, int L);
 int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream);

@@ -1710,5 +1710,6 @@ extern "C" int sd_op_xattn_fused(void* stream, const void* X, const void* R, voi
     XattnArgs a;
     a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
     a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L;
+    if (const char* e = getenv("SD_XATTN_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostic build of the op
     return sd_launch_xattn_fused(a, (hipStream_t)stream);
 }

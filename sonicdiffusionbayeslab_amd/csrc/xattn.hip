@@ -79,6 +79,11 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
     const int NTall = C / 32, nsl = gridDim.y;
     const int jbeg = (int)((long)NTall * blockIdx.y / nsl), NT = (int)((long)NTall * (blockIdx.y + 1) / nsl) - jbeg;
 
+    // diagnostic phase stamps (only with a stamp buffer: tools/xattn_stamps.py); never read by the kernel
+    auto stamp = [&](int i) {
+        if (p.stamps && tid == 0) p.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     // to_out bias -> LDS (before any DMA is in flight: these are the kernel's only ordinary global loads)
     float* sbias = (float*)(smem + RING);
     for (int i = tid; i < C; i += 256) sbias[i] = p.bias[i];
@@ -88,25 +93,29 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
     const int sch = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;              // source chunk byte offset
     const char* aptr = At + (long)(16 * wave + prow) * rowbytes + sch;   // A piece i: + i * 64 rows; pass g: + 320 rows
     const char* xptr = (const char*)p.X + (m0 + 16 * wave + prow) * rowbytes + sch;   // X piece i: + i * 64 rows
-    auto piece1 = [&](int pass, int kt, int i, char* st) {             // i = 0..4: A^T rows, 5..6: X rows
-        if (i < 5) glds16(aptr + ((long)pass * HKEYS + i * 64) * rowbytes + kt * 64, st + (wave + 4 * i) * 1024);
-        else glds16(xptr + (long)(i - 5) * 64 * rowbytes + kt * 64, st + (20 + 4 * (i - 5) + wave) * 1024);
+    // `real` = false: nothing left to fetch -- the piece still issues (the K loop stays one branch-free block with
+    // constant DMA counts; a join would make hipcc drain lgkmcnt in front of the next MFMA) but reads 16 hot bytes
+    const char* dummy = (const char*)p.bias;
+    auto piece1 = [&](int pass, int kt, int i, char* st, bool real) {  // i = 0..4: A^T rows, 5..6: X rows
+        const char* src = i < 5 ? aptr + ((long)pass * HKEYS + i * 64) * rowbytes + kt * 64
+                                : xptr + (long)(i - 5) * 64 * rowbytes + kt * 64;
+        glds16(real ? src : dummy, st + (i < 5 ? wave + 4 * i : 20 + 4 * (i - 5) + wave) * 1024);
     };
     auto issue1 = [&](int pass, int kt, char* st) {
 #pragma unroll
-        for (int i = 0; i < P1_PIECES; ++i) piece1(pass, kt, i, st);
+        for (int i = 0; i < P1_PIECES; ++i) piece1(pass, kt, i, st, true);
     };
     // phase 2: Bw piece q = wave + 4 i (i < 10) covers sub-tile kt = q >> 1 (32 key slots = 64 B), rows 16 (q & 1) .. + 15;
     // pieces 10, 11: residual rows 16 (wave + 4 (i - 10)) .. + 15 of the token tile
     const char* bptr = Bw + (long)(16 * (wave & 1) + prow) * (KEYS * 2) + (wave >> 1) * 64 + sch;   // piece i: + 128 B
     const char* rptr = (const char*)p.R + (m0 + 16 * wave + prow) * rowbytes + sch;                  // piece i: + 64 rows
-    auto piece2 = [&](int j, int i, char* st) {
-        if (i < 10) glds16(bptr + (long)j * 32 * (KEYS * 2) + i * 128, st + (wave + 4 * i) * 1024);
-        else glds16(rptr + (long)(i - 10) * 64 * rowbytes + j * 64, st + BWBYTES + (wave + 4 * (i - 10)) * 1024);
+    auto piece2 = [&](int j, int i, char* st, bool real) {
+        const char* src = i < 10 ? bptr + (long)j * 32 * (KEYS * 2) + i * 128 : rptr + (long)(i - 10) * 64 * rowbytes + j * 64;
+        glds16(real ? src : dummy, st + (i < 10 ? (wave + 4 * i) * 1024 : BWBYTES + (wave + 4 * (i - 10)) * 1024));
     };
     auto issue2 = [&](int j, char* st) {
 #pragma unroll
-        for (int i = 0; i < P2_PIECES; ++i) piece2(j, i, st);
+        for (int i = 0; i < P2_PIECES; ++i) piece2(j, i, st, true);
     };
 
     // ---- fragment read offsets: row r of a 32-row tile, k-step ks: chunk (2 ks + h) ^ ((r >> 2) & 3) ----
@@ -168,13 +177,12 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
             __builtin_amdgcn_sched_barrier(0);
             // The one barrier per K tile sits BETWEEN the two k-steps: by then every wave has left tile kt-1 (its
             // stage is refilled after the barrier) and has retired its own DMA of tile kt+1 (read after the barrier).
-            if (kt + 1 < KT) {
-                if (kt + 3 < KT) wait_vmcnt<2 * P1_PIECES>();   // own pieces of tile kt+1 landed, tiles kt+2, kt+3 may be in flight
-                else if (kt + 2 < KT) wait_vmcnt<P1_PIECES>();
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
+            // in flight at this point: tiles kt+1, kt+2, kt+3 (or their dummies) -> tile kt+1 has landed once at most
+            // 2 x P1_PIECES remain; during the first iterations fewer were issued, the count is then conservative
+            if (KT > 3) wait_vmcnt<2 * P1_PIECES>();    // (tiles 0 .. kt+3 have been issued: prologue + one per iteration)
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             char* refill = smem + (st == 0 ? NSTAGE1 - 1 : st - 1) * STAGE1;   // the stage tile kt-1 was read from = stage of kt+4
             const bool more = kt + 4 < KT;
 #pragma unroll
@@ -183,12 +191,14 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
                 asm("" : "+a"(S[t]));
                 __builtin_amdgcn_sched_barrier(0);
                 if (t == 1 && kt + 1 < KT) frags(smem + sn * STAGE1, fo0, a0, x0);
-                if (t >= 2 && t < 2 + P1_PIECES && more) piece1(pass, kt + 4, t - 2, refill);   // one DMA piece per MFMA gap
+                if (t >= 2 && t < 2 + P1_PIECES) piece1(pass, kt + 4, t - 2, refill, more);   // one DMA piece per MFMA gap
                 __builtin_amdgcn_sched_barrier(0);
             }
             st = sn;
         }
+        stamp(1 + 2 * pass);
         // every wave is done reading this pass's stages -> the next operand stream starts under the softmax
+        wait_vmcnt<0>();                                // (trailing dummy pieces: no two DMAs to one LDS address in flight)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (pass == 0) {
@@ -234,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
                 P[20 * pass + 5 * hd + q] = __builtin_bit_cast(bf16x8, pk);
             }
         }
+        stamp(2 + 2 * pass);
     }
 
     // =============================== phase 2: Y^T = Bw . P^T, 32 channels at a time ===============================
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
             __builtin_amdgcn_sched_barrier(0);
             if (g + NRING < NG) bq[g % NRING] = bfrag(sb, g + NRING);
             else if (jj + 1 < NT) bq[g % NRING] = bfrag(smem + sn * STAGE2, g + NRING - NG);
-            if (g > NG / 2 && g <= NG / 2 + P2_PIECES && more) piece2(j + 2, g - NG / 2 - 1, refill);
+            if (g > NG / 2 && g <= NG / 2 + P2_PIECES) piece2(j + 2, g - NG / 2 - 1, refill, more);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue (LDS operands only): lane holds channels 32 j + 8 g + 4 h + (0..3), g = 0..3, of its token ----
@@ -299,6 +310,7 @@ __global__ __launch_bounds__(256, 1) void xattn_fused_kernel(const XattnArgs p) 
         }
         st = sn;
     }
+    stamp(5);
 }
 
 }  // namespace

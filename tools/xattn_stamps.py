@@ -1,0 +1,40 @@
+"""Where a workgroup of the fused cross-attention kernel spends its cycles: s_memtime stamps at the phase boundaries
+(diagnostic; the stamp buffer's address is handed to the operator entry point through SD_XATTN_STAMPS).  Development tool."""
+import os, sys, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sonicdiffusionbayeslab_amd import _lib
+
+B, hw, C = (int(x) for x in (sys.argv[1:4] or (16, 4096, 320)))
+M = B * hw
+lib = _lib.load()
+st = torch.cuda.current_stream().cuda_stream
+bf = torch.bfloat16
+x, r = torch.randn(M, C, device="cuda").to(bf), torch.randn(M, C, device="cuda").to(bf)
+at = (torch.randn(B, 640, C, device="cuda") / math.sqrt(C)).to(bf)
+bw = (torch.randn(B, C, 640, device="cuda") / 25).to(bf)
+bias = torch.randn(C, device="cuda")
+y = torch.empty(M, C, device="cuda", dtype=bf)
+nwg = M // 128 * 4
+stamps = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+call = lambda: _lib.check(lib.sd_op_xattn_fused(st, x.data_ptr(), r.data_ptr(), y.data_ptr(), at.data_ptr(), bw.data_ptr(),
+                                                bias.data_ptr(), M, C, hw, 77))
+for _ in range(3):
+    call()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(10):
+    call()
+e.record(); torch.cuda.synchronize()
+print(f"B={B} hw={hw} C={C}: {s.elapsed_time(e) / 10 * 1e3:.1f} us per launch (no stamps)")
+os.environ["SD_XATTN_STAMPS"] = str(stamps.data_ptr())
+call(); torch.cuda.synchronize()
+t = stamps.cpu().view(-1, 8)
+t = t[t[:, 5] != 0]
+names = ["phase1 pass0", "softmax0", "phase1 pass1", "softmax1", "phase2"]
+d = (t[:, 1:6] - t[:, 0:5]).double()
+print(f"{t.shape[0]} workgroups; cycles per workgroup (s_memtime ticks, mean / max):")
+for i, n in enumerate(names):
+    print(f"  {n:14s} {d[:, i].mean():10.0f} {d[:, i].max():10.0f}")
+print(f"  total          {(t[:, 5] - t[:, 0]).double().mean():10.0f}; launch span {(t[:, 5].max() - t[:, 0].min()).item()} ticks")
