@@ -191,9 +191,10 @@ int sd_op_time_embedding(void* stream, float t, const void* W1, const float* b1,
 
 /* Fused prompt cross-attention of one transformer block (src/models.py:227-235 -> diffusers Attention over the 77 prompt
  * keys): Y = R + sum_h softmax_L(X A_h) B_h + b_o in ONE launch, probabilities kept in registers.  8 heads x 80 key
- * slots.  At [samples][640][C] bf16: row (head, slot) = scale * K_h[slot] . W_q,h (zero rows for slots >= L);
- * Bw [samples][C][640] bf16: row = output channel, columns (head, slot) with bits 2 and 3 of the slot index swapped
- * inside every group of 16 (the order in which an MFMA accumulator tile is consumed as the next product's operand).
+ * slots.  A^T row (head, slot) = scale * K_h[slot] . W_q,h over the C channels (zero rows for slots >= L); Bw row =
+ * output channel, columns (head, slot) with bits 2 and 3 of the slot index swapped inside every group of 16 (the order in
+ * which an MFMA accumulator tile is consumed as the next product's operand).  Both are passed TILED so that every
+ * LDS-DMA piece of the kernel is one contiguous KiB: At [samples][C/32][640][32], Bw [samples][C/32][20][32][32] (bf16).
  * sd_unet_set_context builds both from the prompt.  M tokens, rows_per_sample tokens per sample (multiple of 128). */
 int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                       const float* bias, int M, int C, int rows_per_sample, int L);

@@ -20,7 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # attention is VALU-bound: keep MFMA results in arch VGPRs (no v_accvgpr_read/write copies)
 # and let fmaxf lower to bare v_max/v_max3 (no canonicalising v_max x,x in front of each operand;
 # the kernel masks with -1e30, never with inf/NaN)
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
+               # fused cross-attention: 160 accumulators + the softmax on them in ONE 256-register pool
+               "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(a: str, b: str) -> bool:

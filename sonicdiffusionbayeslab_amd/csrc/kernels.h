@@ -103,13 +103,16 @@ int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t str
 // accumulator tile is consumed as the next product's operand, see xattn.hip)
 int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream, int perm16 = 0);
 
+int sd_launch_retile32(const bf16_t* src, bf16_t* dst, int B, int R, int K, int RT, hipStream_t stream);
+
 // xattn.hip: fused prompt cross-attention  Y = R + sum_h softmax_L(X A_h) B_h + b_o  (one launch per block)
 struct XattnArgs {
     const bf16_t* X = nullptr;    // [M, C] LayerNorm output
     const bf16_t* R = nullptr;    // [M, C] residual
     bf16_t* Y = nullptr;          // [M, C]
-    const bf16_t* At = nullptr;   // [samples][640][C]: row (head, key slot) = scale * K_h[key] . W_q,h, zero rows for slots >= L
-    const bf16_t* Bw = nullptr;   // [samples][C][640]: row = output channel, (head, key slot) contiguous in PERMUTED k order
+    // TILED operands (sd_launch_retile32): a 16-row x 64-byte DMA piece is one contiguous KiB
+    const bf16_t* At = nullptr;   // [samples][C/32][640][32]: row (head, key slot) = scale * K_h[key] . W_q,h, zero rows for slots >= L
+    const bf16_t* Bw = nullptr;   // [samples][C/32][20][32][32]: (channel tile, 32-slot slice, channel, slot in PERMUTED k order)
     const float* bias = nullptr;  // [C] to_out bias
     int M = 0, C = 0, rows_per_sample = 0, L = 0;
     unsigned long long* stamps = nullptr;   // diagnostic: 8 s_memtime stamps per workgroup (SD_XATTN_STAMPS), else null

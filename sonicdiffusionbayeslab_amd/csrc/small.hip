@@ -248,6 +248,29 @@ int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int C
     return 0;
 }
 
+// dst[b][R / RT][K / 32][RT][32] = src[b][R][K] (bf16): every (row tile, 32-column slice) becomes RT contiguous 64-byte
+// rows, so that a 16-row x 64-byte LDS-DMA piece of the fused cross-attention kernel is ONE contiguous KiB (8 full cache
+// lines) instead of 16 half lines at the row stride.  One 16-byte chunk per thread.
+__global__ void retile32_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int K, int RT) {
+    const long per = (long)R * K / 8;                            // 16-byte chunks per sample
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const int b = blockIdx.y;
+    const int kc = (int)(i % (K / 8)), row = (int)(i / (K / 8));  // source chunk (row, 8 columns)
+    const int ks = kc >> 2, cc = kc & 3;                          // 32-column slice, chunk inside it
+    const long d = ((((long)(row / RT) * (K / 32) + ks) * RT + row % RT) * 4 + cc);
+    const u32x4 v = *(const u32x4*)(src + ((long)b * R * K) + (long)row * K + kc * 8);
+    *(u32x4*)(dst + ((long)b * R * K) + d * 8) = v;
+}
+
+int sd_launch_retile32(const bf16_t* src, bf16_t* dst, int B, int R, int K, int RT, hipStream_t stream) {
+    SD_REQUIRE(src && dst && B > 0 && B <= 65535 && K % 32 == 0 && RT > 0 && R % RT == 0, "retile32: B=%d R=%d K=%d RT=%d", B, R, K, RT);
+    const long per = (long)R * K / 8;
+    hipLaunchKernelGGL(retile32_kernel, dim3((unsigned)((per + 255) / 256), B), dim3(256), 0, stream, src, dst, R, K, RT);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int sd_launch_xattn_expand(const bf16_t* kv, bf16_t* out, int B, int L, int C, int NH, int col_off, float scale,
                            hipStream_t stream) {
     SD_REQUIRE(kv && out && B > 0 && L > 0 && L <= 80 && NH > 0 && C % NH == 0 && (C / NH) % 2 == 0,

@@ -929,7 +929,7 @@ struct Builder {
         const int L = c.context_len;
         pl.ctx_bf16 = tensor((size_t)UB * L * c.cross_attention_dim * 2, true);
         // masked K / V expansions used by sd_unet_set_context for the folded cross-attention (sized for the widest level)
-        pl.ctx_fold_scratch = tensor((size_t)2 * UB * c.num_heads * 80 * c.block_out_channels[nl - 1] * 2, true);
+        pl.ctx_fold_scratch = tensor((size_t)3 * UB * c.num_heads * 80 * c.block_out_channels[nl - 1] * 2, true);
         // ---- time embedding (M = 1: the reference passes one scalar t per call) ----
         int t_sin = tensor((size_t)c0 * 4), t_h1 = tensor((size_t)temb * 4), t_emb = tensor((size_t)temb * 4);
         int t_proj = tensor((size_t)u->tproj_total * 4);
@@ -1403,13 +1403,19 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
         bf16_t* vexp = kexp + (size_t)unet_batch * NP * C;
         if ((rc = sd_launch_xattn_expand(kvp, kexp, unet_batch, L, C, NH, 0, 1.0f / sqrtf((float)d), (hipStream_t)stream))) return rc;
         if ((rc = sd_launch_xattn_expand(kvp, vexp, unet_batch, L, C, NH, C, 1.0f, (hipStream_t)stream))) return rc;
+        // fused kernel: both operands are re-tiled ([32-column slice][rows][64 B]) so that its DMA pieces are contiguous;
+        // the plain layouts land in the V expansion's scratch first (free after the second GEMM below has read it ... the
+        // A^T GEMM output goes there BEFORE that GEMM runs, so it is re-tiled right away)
+        bf16_t* at_dst = (bf16_t*)(ws + pl.tensors[f.at].off);
+        bf16_t* tmp = (bf16_t*)(ws + pl.tensors[pl.ctx_fold_scratch].off) + (size_t)2 * unet_batch * NP * C;   // third scratch slab
         {   // A^T [UB*NP, C]: rows (sample, head, key), K-contiguous over the UNet channel -> W operand of GEMM 1
             GemmArgs a;
             a.X = kexp; a.ldx = C; a.K1 = C; a.K = C; a.M = unet_batch * NP; a.N = C;
             a.W = (const bf16_t*)(u->dweights + f.wqT);
-            a.C = (bf16_t*)(ws + pl.tensors[f.at].off); a.ldc = C;
+            a.C = f.perm ? tmp : at_dst; a.ldc = C;
             a.zero_page = g_zero_page;
             if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
+            if (f.perm && (rc = sd_launch_retile32(tmp, at_dst, unet_batch, NP, C, NP, (hipStream_t)stream))) return rc;
         }
         {   // B^T [UB*NP, C] = V_masked . W_o^T (one GEMM, into the K expansion's scratch), then transposed per sample
             // to [C, NP]: K-contiguous over (head, key) -> W operand of GEMM 2
@@ -1419,9 +1425,10 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
             a.C = kexp; a.ldc = C;
             a.zero_page = g_zero_page;
             if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
-            if ((rc = sd_launch_transpose_bf16(kexp, (bf16_t*)(ws + pl.tensors[f.bw].off), unet_batch, NP, C, (hipStream_t)stream,
-                                               f.perm ? 1 : 0)))
+            bf16_t* bw_dst = (bf16_t*)(ws + pl.tensors[f.bw].off);
+            if ((rc = sd_launch_transpose_bf16(kexp, f.perm ? tmp : bw_dst, unet_batch, NP, C, (hipStream_t)stream, f.perm ? 1 : 0)))
                 return rc;
+            if (f.perm && (rc = sd_launch_retile32(tmp, bw_dst, unet_batch, C, NP, 32, (hipStream_t)stream))) return rc;
         }
     }
     return 0;

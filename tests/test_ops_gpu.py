@@ -358,9 +358,12 @@ def test_xattn_fused(sdlib, B, hw, C, spike):
     perm = (slot & ~12) | ((slot & 4) << 1) | ((slot & 8) >> 1)
     Bw = torch.zeros(B, C, H * 80)
     Bw[:, :, perm] = Bn.transpose(1, 2)
+    # tiled operand layouts (one contiguous KiB per 16-row x 64-byte DMA piece): A^T [C/32][640][32], Bw [C/32][20][32][32]
+    At_t = At.view(B, H * 80, C // 32, 32).permute(0, 2, 1, 3).contiguous()
+    Bw_t = Bw.view(B, C // 32, 32, 20, 32).permute(0, 1, 3, 2, 4).contiguous()
     out = torch.full((M, C), float("nan"), device="cuda", dtype=torch.bfloat16)
-    _lib.check(sdlib.sd_op_xattn_fused(stream(), P(x, torch.bfloat16), P(r, torch.bfloat16), P(out), P(At, torch.bfloat16),
-                                       P(Bw.contiguous(), torch.bfloat16), P(bo), M, C, hw, L))
+    _lib.check(sdlib.sd_op_xattn_fused(stream(), P(x, torch.bfloat16), P(r, torch.bfloat16), P(out), P(At_t, torch.bfloat16),
+                                       P(Bw_t, torch.bfloat16), P(bo), M, C, hw, L))
     torch.cuda.synchronize()
     e1, e2 = rel_l2(out, ref_fold), rel_l2(out, ref_attn)
     print(f"xattn fused B={B} hw={hw} C={C}: vs folded fp32 {e1:.3e}, vs SDPA + linears {e2:.3e}")

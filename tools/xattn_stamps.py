@@ -11,8 +11,8 @@ lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 bf = torch.bfloat16
 x, r = torch.randn(M, C, device="cuda").to(bf), torch.randn(M, C, device="cuda").to(bf)
-at = (torch.randn(B, 640, C, device="cuda") / math.sqrt(C)).to(bf)
-bw = (torch.randn(B, C, 640, device="cuda") / 25).to(bf)
+at = (torch.randn(B, C // 32, 640, 32, device="cuda") / math.sqrt(C)).to(bf)
+bw = (torch.randn(B, C // 32, 20, 32, 32, device="cuda") / 25).to(bf)
 bias = torch.randn(C, device="cuda")
 y = torch.empty(M, C, device="cuda", dtype=bf)
 nwg = M // 128 * 4
@@ -38,3 +38,6 @@ print(f"{t.shape[0]} workgroups; cycles per workgroup (s_memtime ticks, mean / m
 for i, n in enumerate(names):
     print(f"  {n:14s} {d[:, i].mean():10.0f} {d[:, i].max():10.0f}")
 print(f"  total          {(t[:, 5] - t[:, 0]).double().mean():10.0f}; launch span {(t[:, 5].max() - t[:, 0].min()).item()} ticks")
+print(f"  8-wave kernel: phase 1 (incl. first-tile latency) {(t[:, 1] - t[:, 0]).double().mean():.0f}; softmax "
+      f"{(t[:, 2] - t[:, 1]).double().mean():.0f}; exchange {(t[:, 3] - t[:, 2]).double().mean():.0f}; phase 2 "
+      f"{(t[:, 5] - t[:, 3]).double().mean():.0f}")
