@@ -117,16 +117,29 @@ def end_to_end(model, args, dev):
     return best
 
 
-TRAFFIC_SOURCE = ("profiles/round1_conv_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+TRAFFIC_SOURCE = ("profiles/round2_conv_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                   "tools/run_traffic.sh; NOT measured in this run)")
+PMC_SOURCE = ("profiles/round2_pmc_forward.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of "
+              "tools/run_pmc_forward.sh; NOT measured in this run)")
+
+
+def conv_mfma_busy():
+    """MFMA-busy fraction of the dominant kernel from the committed PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+    shader cycles of the dispatch); None if the file is absent."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_forward.json")
+    try:
+        with open(p) as f:
+            return float(json.load(f)["conv_halo_kernel<0>"]["mfma_busy_frac"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def conv_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/run_traffic.sh ->
-    profiles/round1_conv_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the 50 conv launches of
+    profiles/round2_conv_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the 50 conv launches of
     one forward at this bench shape).  PMC counters cannot be read live inside this process, so the number is
     the profile's; None if the file is absent."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_conv_traffic.json")
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_conv_traffic.json")
     try:
         with open(p) as f:
             return float(json.load(f)["hbm_bytes_per_launch"])
@@ -302,6 +315,7 @@ def main():
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": None if fp8 else conv_traffic_bytes(),
                            "traffic_source": None if fp8 else TRAFFIC_SOURCE,
+                           "mfma_busy": None if fp8 else conv_mfma_busy(), "mfma_busy_source": None if fp8 else PMC_SOURCE,
                            "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
                            "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
         tot = sum(v["ms"] for v in prof.values())
