@@ -11,7 +11,7 @@ import re
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsdhip.so")
+LIB_PATH = os.environ.get("SD_AMD_LIB", os.path.join(HERE, "lib", "libsdhip.so"))   # (SD_AMD_LIB: A/B builds of the kernels)
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "sd_hip.h"))
 
 _lib: Optional[C.CDLL] = None

@@ -214,11 +214,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             const char* hcur = hsel ? Hb1 : Hb0;
             char* hnext = hsel ? Hb0 : Hb1;
             const bool more = s + 1 < s_end;
-            // The 36 fragment addresses (9 taps x 4 pixel tiles) do not depend on the slice; hoisted out of this loop
-            // they cost 36 VGPRs and push the DMA descriptors into scratch, whose reloads drain the counted vmcnt
-            // pipeline.  Recomputing them per tap is ~6 VALU per address under 640-1280 cycles of MFMA.
+            // The 36 fragment addresses (9 taps x 4 pixel tiles) do not depend on the slice and hipcc hoists them out of
+            // this loop (36 VGPRs).  bf16: keep the hoist -- measured 3-5 % faster than recomputing them per tap although
+            // it costs 14 spilled descriptors (tools/ab_halo.sh, same box, interleaved).  fp8: the 32-byte fragments leave
+            // no room (73 spills, reloads inside the tap loop drain the counted vmcnt pipeline), so there the values are
+            // made opaque per slice and the addresses are recomputed under the MFMAs.
+            if (DT) {
 #pragma unroll
-            for (int f = 0; f < TM; ++f) asm volatile("" : "+v"(hbase[f]), "+v"(hrc[f]));
+                for (int f = 0; f < TM; ++f) asm volatile("" : "+v"(hbase[f]), "+v"(hrc[f]));
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 // In-order vmcnt: tile kt's W stage (issued two K tiles ago) and, at tap 0, the slice's halo have
