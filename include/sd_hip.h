@@ -178,6 +178,12 @@ int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias,
                   void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample);
 int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
                     const float* beta, void* y, int B, int HW, int groups, float eps, int silu);
+/* conv3x3 (stride 1) -> GroupNorm(+SiLU) the way the forward plan runs every resnet's conv -> norm pair
+ * (diffusers ResnetBlock2D, reached from src/models.py:227): the conv's epilogue leaves per-64-pixel-block channel sums
+ * and the GroupNorm takes its statistics from them instead of re-reading Y.  Y = conv output, Yn = normalised output. */
+int sd_op_conv3x3_groupnorm(void* stream, const void* X, const void* W, const float* bias, const float* bias2,
+                            const void* R, void* Y, int B, int Hin, int Win, int Cin, int Cout, const float* gamma,
+                            const float* beta, void* Yn, int groups, float eps, int silu);
 int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows, int C,
                     float eps);
 int sd_op_attention(void* stream, const void* Q, long long ldq, const void* K, long long ldk, const void* V,

@@ -88,6 +88,50 @@ __device__ __forceinline__ f32x2_t geglu_pair(f32x2_t value, f32x2_t gate) {
     return value * gate * phi;
 }
 
+// ---- GroupNorm statistics from the PRODUCER's epilogue -------------------------------------------------------------
+// A wave of the GEMM / conv kernels owns 64 consecutive output rows x TN 16-column tiles (accumulator layout: lane
+// (lrow = lane & 15, lq = lane >> 4) holds columns 16 a + 4 lq + (0..3) of row 16 b + lrow).  This writes, per 64-row block
+// and channel, the sum and the sum of squares of the bf16-ROUNDED outputs (what GroupNorm will read) to
+// stats[(block64 * C + channel) * 2 + {0, 1}]; the consuming GroupNorm reduces blocks and channels per group in a fixed
+// order (deterministic), so the statistics pass over the tensor disappears.  Rows >= M are excluded, columns >= N skipped.
+template <int SHR>
+__device__ __forceinline__ float row_shr_add(float v) {      // v[i] += v[i - SHR] inside each row of 16 lanes (0 shifted in)
+    const int sh = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SHR, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, sh);
+}
+template <int TN, int TM>
+__device__ __forceinline__ void tile_channel_stats(const f32x4 (&acc)[TN][TM], float* __restrict__ stats, long block64, int C,
+                                                   int n_base, int N, int m_base, int M, int lane) {
+    const int lrow = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const bool live = m_base + b * 16 + lrow < M;
+            const unsigned p0 = pack2bf(acc[a][b][0], acc[a][b][1]), p1 = pack2bf(acc[a][b][2], acc[a][b][3]);
+            const float v[4] = {bflo(p0), bfhi(p0), bflo(p1), bfhi(p1)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = live ? v[j] : 0.f;
+                sv[j] += x;
+                qv[j] = __builtin_fmaf(x, x, qv[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sv[j] = row_shr_add<8>(row_shr_add<4>(row_shr_add<2>(row_shr_add<1>(sv[j]))));
+            qv[j] = row_shr_add<8>(row_shr_add<4>(row_shr_add<2>(row_shr_add<1>(qv[j]))));
+        }
+        const int n = n_base + a * 16 + lq * 4;
+        if (lrow == 15 && n < N) {
+            float* o = stats + (block64 * C + n) * 2;
+            *(f32x4*)o = f32x4{sv[0], qv[0], sv[1], qv[1]};
+            *(f32x4*)(o + 4) = f32x4{sv[2], qv[2], sv[3], qv[3]};
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, hb);
             issue_w(s_begin * 9, Wb + wst * WBYTES);
             issue_w(s_begin * 9 + 1, Wb + (wst == 2 ? 0 : wst + 1) * WBYTES);
-            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N);
+            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N) && !p.stats;
         }
 
         // ---- epilogue, phase B: stores only ----------------------------------------------------------------
@@ -364,6 +364,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 }
             }
         } else {
+            // GroupNorm statistics of this tile for the consuming GroupNorm (64-row blocks = this wave's rows)
+            if (p.stats) tile_channel_stats<TN, TM>(acc, p.stats, (em0 + wm * WTM) >> 6, p.N, en0 + wn * WTN, p.N, em0 + wm * WTM, p.M, lane);
             // v_permlane16_swap pairs two adjacent 16-channel tiles: 16 contiguous bytes per lane and store
             auto store_narrow = [&](int a) {
                 const int n = en0 + wn * WTN + a * 16 + lq * 4;

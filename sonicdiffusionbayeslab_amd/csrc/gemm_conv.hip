@@ -405,7 +405,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             primed = true;
             // phase B issues exactly EPI_STORES stores per wave iff the finished tile is full
             stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && (p.ldc & 7) == 0 && p.splitk == 1 &&
-                             !(p.tune & (32 | 64 | 8)) && !p.out_fp8;
+                             !(p.tune & (32 | 64 | 8)) && !p.out_fp8 && !p.stats;
         }
     }
 
@@ -425,6 +425,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             }
         }
     } else if (EPI == EPI_STD || EPI == EPI_SOFTMAX) {
+        // GroupNorm statistics of this tile for the consuming GroupNorm (64-row blocks = this wave's rows; WTM == 64)
+        if (EPI == EPI_STD && WTM == 64 && p.stats)
+            tile_channel_stats<TN, TM>(acc, p.stats, (em0 + wm * WTM) >> 6, p.N, en0 + wn * WTN, p.N, em0 + wm * WTM, p.M, lane);
         // Stores are issue-bound (one 8-B store per lane per 16x16 tile): v_permlane16_swap pairs two
         // adjacent tiles so that every lane owns 16 contiguous bytes -> half the store instructions,
         // 64 contiguous bytes per row per instruction.  After the swap lane group lq holds
@@ -616,7 +619,15 @@ static int check_fp8(const GemmArgs& a, const char* what) {
     return 0;
 }
 
+static int check_stats(const GemmArgs& a, int epi) {
+    if (!a.stats) return 0;
+    SD_REQUIRE(epi == EPI_STD && a.M % 64 == 0 && !(a.splitk > 1 && a.slab) && !a.out_fp8,
+               "producer statistics: plain epilogue, M %% 64 == 0 and no split-K (M=%d splitk=%d)", a.M, a.splitk);
+    return 0;
+}
+
 int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
+    if (check_stats(a, epi)) return -1;
     if (a.dt == 1) {
         if (check_fp8(a, "gemm")) return -1;
         SD_REQUIRE(a.N % 4 == 0 && a.M > 0 && a.N > 0 && a.zero_page, "gemm fp8: bad problem");
@@ -659,6 +670,7 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
 }
 
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
+    if (check_stats(a, EPI_STD)) return -1;
     if (a.dt == 1) {
         if (check_fp8(a, "conv3x3")) return -1;
         SD_REQUIRE(a.Cin % 128 == 0, "conv3x3 fp8: Cin=%d must be a multiple of 128 (pad the channels)", a.Cin);

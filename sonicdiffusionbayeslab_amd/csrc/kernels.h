@@ -32,6 +32,9 @@ struct GemmArgs {
     int sm_valid = 0;                 // EPI 2: softmax over the first sm_valid of every 80 output columns
     int tiles_m = 0, tiles_n = 0;     // filled by the launcher
     int tune = 0;                     // experiment knobs, filled by the launcher from SD_GEMM_TUNE
+    // GroupNorm statistics of the output from this kernel's epilogue (split-K = 1 only): [M / 64][N][2] fp32 partial
+    // sums / sums of squares per 64-row block and channel (common.h::tile_channel_stats); null = off
+    float* stats = nullptr;
     // fp8-e4m3 operands (dt = 1): X and W hold OCP e4m3 bytes, K (and ldx / ldw / Cin) count fp8 elements and are
     // multiples of 128; the epilogue multiplies the fp32 sums by wscale[n] * xscale_inv before bias / residual.
     int dt = 0;
@@ -60,12 +63,16 @@ struct GroupNormArgs {
     // pad channels are written as zeros: they are the K tail of the fp8 GEMM / conv that consumes y)
     int out_fp8 = 0, Cpad = 0;
     float oscale = 1.0f;
+    // statistics delivered by the producers of x1 / x2 ([B * HW / 64][C1 or C2][2], see GemmArgs::stats): the statistics
+    // pass over the tensor is skipped (both must be given when C2 > 0; HW a multiple of 64)
+    const float* stats1 = nullptr; const float* stats2 = nullptr;
     float* partial = nullptr;   // workspace of sd_groupnorm_scratch_bytes(): [B,nsplit,groups,2] partials + [B,groups,2] stats
     int B = 0, HW = 0, groups = 32, nsplit = 0;
     float eps = 1e-5f;
     int silu = 0;
 };
 int sd_groupnorm_nsplit(int B, int HW);
+bool sd_groupnorm_uses_small(int B, int HW, int C1, int C2, int groups);
 size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups);
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream);
 

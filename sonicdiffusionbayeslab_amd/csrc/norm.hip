@@ -117,6 +117,36 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormArgs a)
     }
 }
 
+// Statistics delivered by the producers (GemmArgs::stats): per 64-row block and channel (sum, sum of squares).  One
+// wave per (batch, group) sums its channels over the blocks of its sample in a fixed order -> mean, rstd, written where
+// gn_apply_kernel reads them.  Replaces gn_stats_kernel + gn_finalize_kernel (no pass over the tensor).
+__global__ __launch_bounds__(256) void gn_finalize_stats_kernel(const GroupNormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= a.B * a.groups) return;
+    const int b = idx / a.groups, gi = idx - b * a.groups;
+    const int C = a.C1 + a.C2, cpg = C / a.groups, nblk = a.HW >> 6;
+    const int total = nblk * cpg;                       // (block, channel) pairs of this group
+    float s = 0.f, q = 0.f;
+    for (int i = lane; i < total; i += 64) {
+        const int blk = i / cpg, c = gi * cpg + (i - blk * cpg);
+        const long gb = (long)b * nblk + blk;
+        const float* pp = c < a.C1 ? a.stats1 + (gb * a.C1 + c) * 2 : a.stats2 + (gb * a.C2 + (c - a.C1)) * 2;
+        s += pp[0];
+        q += pp[1];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const float cnt = (float)a.HW * (float)cpg;
+        const float mean = s / cnt;
+        const float var = fmaxf(q / cnt - mean * mean, 0.f);
+        float* st = a.partial + (long)a.B * a.nsplit * a.groups * 2 + (long)idx * 2;
+        st[0] = mean;
+        st[1] = rsqrtf(var + a.eps);
+    }
+}
+
 __global__ void gn_apply_kernel(const GroupNormArgs a) {
     const GnGeom g = gn_geom(a.C1 + a.C2, a.groups);
     const int tid = threadIdx.x;
@@ -448,6 +478,13 @@ int sd_groupnorm_nsplit(int B, int HW) {
     return n;
 }
 
+// the single-launch small-image kernel takes this instance (it needs no producer statistics)
+bool sd_groupnorm_uses_small(int B, int HW, int C1, int C2, int groups) {
+    static const bool no_small = getenv("SD_GN_NO_SMALL") != nullptr;
+    const int C = C1 + C2;
+    return !no_small && HW <= 256 && (long)HW * (C / groups) <= 10240 && (C / groups) % 4 == 0 && C1 % 4 == 0 && B <= 65535;
+}
+
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const int C = a.C1 + a.C2;
     SD_REQUIRE(a.x1 && a.y && a.gamma && a.beta && a.partial, "groupnorm: null operand");
@@ -460,15 +497,19 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     SD_REQUIRE(a.nsplit >= 1 && a.nsplit <= a.HW && a.B > 0 && a.HW > 0, "groupnorm: bad split %d for HW=%d", a.nsplit, a.HW);
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
-    static const bool no_small = getenv("SD_GN_NO_SMALL") != nullptr;
-    if (!no_small && a.HW <= 256 && (long)a.HW * (C / a.groups) <= 10240 && (C / a.groups) % 4 == 0 && a.C1 % 4 == 0 && a.B <= 65535) {
+    if (sd_groupnorm_uses_small(a.B, a.HW, a.C1, a.C2, a.groups)) {
         hipLaunchKernelGGL(gn_small_kernel, dim3(a.groups, a.B), dim3(256), 0, stream, a);
         SD_CHECK_HIP(hipGetLastError());
         return 0;
     }
     dim3 grid(a.nsplit, a.B);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), (g.threads + g.nchunks) * sizeof(float4), stream, a);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
+    if (a.stats1 != nullptr) {
+        SD_REQUIRE(a.HW % 64 == 0 && (a.C2 == 0 || a.stats2 != nullptr), "groupnorm: producer statistics need HW %% 64 == 0 and both sources");
+        hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), (g.threads + g.nchunks) * sizeof(float4), stream, a);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
+    }
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;

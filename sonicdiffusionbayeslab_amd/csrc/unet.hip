@@ -109,6 +109,9 @@ struct Op {
     // the per-output-channel weight scales, xs = activation scale of its input; out_fp8: the op WRITES e4m3
     // (rows of Cpad bytes) with scale os.  Kalg: unpadded contraction length (algorithmic FLOPs).
     int dt = 0, out_fp8 = 0, Cpad = 0, Kalg = 0;
+    // GroupNorm statistics from the producer's epilogue: `stats` = tensor this op writes ([M/64][N][2] fp32),
+    // s1 / s2 = the statistics tensors of a GroupNorm's sources (it then skips its statistics pass)
+    int stats = -1, s1 = -1, s2 = -1;
     size_t wsc = NOFF;
     float xs = 1.f, os = 1.f;
     int nwrap = 0;
@@ -674,6 +677,14 @@ struct Builder {
     Plan& pl;
     int UB;
     std::vector<Wrap> wrapstack;
+    std::map<int, int> stats_of;      // activation tensor -> statistics tensor written by its producer
+    // SD_GN_PRODUCER_STATS=0: every GroupNorm runs its own statistics pass (round-1 behaviour)
+    bool producer_stats = !(getenv("SD_GN_PRODUCER_STATS") && atoi(getenv("SD_GN_PRODUCER_STATS")) == 0);
+    void want_stats(Op& o, int M, int N) {      // called for producers whose output feeds a GroupNorm
+        if (!producer_stats || u->kind != 0 || o.splitk > 1 || M % 64 != 0 || o.epi != 0 || o.rpb != 0) return;
+        o.stats = tensor((size_t)(M / 64) * N * 2 * 4);
+        stats_of[o.out] = o.stats;
+    }
 
     int tensor(size_t bytes, bool persistent = false) {
         Tn t;
@@ -701,6 +712,11 @@ struct Builder {
         o.g = W(g); o.be = W(b); o.eps = eps; o.silu = silu;
         o.nsplit = sd_groupnorm_nsplit(UB, hw);
         o.aux = tensor(sd_groupnorm_scratch_bytes(UB, hw, u->cfg.norm_num_groups));
+        if (hw % 64 == 0 && !sd_groupnorm_uses_small(UB, hw, c1, c2, u->cfg.norm_num_groups) && stats_of.count(x1) &&
+            (x2 < 0 || stats_of.count(x2))) {
+            o.s1 = stats_of[x1];
+            o.s2 = x2 >= 0 ? stats_of[x2] : -1;
+        }
         if (fq) { o.out_fp8 = 1; o.Cpad = pad128(c1 + c2); o.os = u->s_norm; o.out = tensor((size_t)UB * hw * o.Cpad); }
         else o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
         push(o);
@@ -720,6 +736,7 @@ struct Builder {
         o.splitk = sd_conv3x3_splitk(o.M, o.N, o.Cin, hin, hin, stride, up, o.dt);
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * o.M * o.N * 4);
         o.out = tensor((size_t)o.M * cout * 2);
+        want_stats(o, o.M, cout);         // every 3x3 conv of the UNet feeds a GroupNorm (directly or as a skip)
         push(o);
         return o.out;
     }
@@ -816,7 +833,11 @@ struct Builder {
         int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias", fq);
         int ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, sn, sf);
         int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, sf);
-        return gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
+        const int out = gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
+        if (pl.ops.back().splitk == 1) {          // the block's output feeds the next resnet's GroupNorm
+            want_stats(pl.ops.back(), M, C);
+        }
+        return out;
     }
 
     // ---- AutoencoderKL decoder: latents/scale -> post_quant_conv -> decoder -> image ----
@@ -1016,9 +1037,9 @@ bool wrap_skipped(const Wrap& w, int branch) {
     return w.type == 0 ? w.layer_i >= cache_layer_id : w.layer_i > cache_layer_id;
 }
 
-void op_tensors(const Op& o, int ins[6], int& nin) {
+void op_tensors(const Op& o, int ins[8], int& nin) {
     nin = 0;
-    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt})
+    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt, o.s1, o.s2})
         if (t >= 0) ins[nin++] = t;
 }
 
@@ -1031,11 +1052,13 @@ void assign_memory(sd_unet* u, Plan& pl) {
             for (int k = 0; k < pl.ops[i].nwrap; ++k)
                 if (wrap_skipped(pl.ops[i].wraps[k], pl.branch)) pl.skipped[i] = 1;
         std::vector<int> producer(pl.tensors.size(), -1);
-        for (int i = 0; i < nops; ++i)
+        for (int i = 0; i < nops; ++i) {
             if (pl.ops[i].out >= 0) producer[pl.ops[i].out] = i;
+            if (pl.ops[i].stats >= 0) producer[pl.ops[i].stats] = i;
+        }
         for (int i = 0; i < nops; ++i) {
             if (pl.skipped[i]) continue;
-            int ins[6], nin;
+            int ins[8], nin;
             op_tensors(pl.ops[i], ins, nin);
             for (int k = 0; k < nin; ++k) {
                 const int p = producer[ins[k]];
@@ -1048,10 +1071,10 @@ void assign_memory(sd_unet* u, Plan& pl) {
     // lifetimes over the full plan
     for (int i = 0; i < nops; ++i) {
         const Op& o = pl.ops[i];
-        int ins[6], nin;
+        int ins[8], nin;
         op_tensors(o, ins, nin);
         for (int k = 0; k < nin; ++k) pl.tensors[ins[k]].last = std::max(pl.tensors[ins[k]].last, i);
-        for (int t : {o.out, o.aux})
+        for (int t : {o.out, o.aux, o.stats})
             if (t >= 0) {
                 if (pl.tensors[t].def < 0) pl.tensors[t].def = i;
                 pl.tensors[t].last = std::max(pl.tensors[t].last, i);
@@ -1132,6 +1155,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.y = (bf16_t*)T(o.out); a.partial = (float*)T(o.aux);
             a.B = o.B; a.HW = o.HW; a.groups = u->cfg.norm_num_groups; a.nsplit = o.nsplit; a.eps = o.eps; a.silu = o.silu;
             a.out_fp8 = o.out_fp8; a.Cpad = o.Cpad; a.oscale = o.os;
+            a.stats1 = (const float*)T(o.s1); a.stats2 = (const float*)T(o.s2);
             return sd_launch_groupnorm(a, stream);
         }
         case OP_CONV3: {
@@ -1143,6 +1167,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.Hin = o.Hin; a.Win = o.Win; a.Cin = o.Cin; a.Hout = o.Hout; a.Wout = o.Wout; a.stride = o.stride; a.up = o.up;
             a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
             if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
+            a.stats = (float*)T(o.stats);
             return sd_launch_conv3x3(a, stream);
         }
         case OP_GEMM: {
@@ -1157,6 +1182,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.w_batch_stride = o.wbs; a.rows_per_batch = o.rpb; a.sm_valid = o.sm_valid;
             if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
             if (o.out_fp8) { a.out_fp8 = 1; a.oscale = o.os; a.ldc = o.Cpad; }
+            a.stats = (float*)T(o.stats);
             return sd_launch_gemm(a, o.epi, stream);
         }
         case OP_LN:
@@ -1612,6 +1638,32 @@ extern "C" int sd_op_groupnorm(void* stream, const void* x1, int C1, const void*
     a.partial = (float*)op_scratch(sd_groupnorm_scratch_bytes(B, HW, groups));
     SD_REQUIRE(a.partial, "sd_op_groupnorm: cannot allocate scratch");
     return sd_launch_groupnorm(a, (hipStream_t)stream);
+}
+
+// conv3x3 -> GroupNorm(+SiLU) as the plan runs the pair: the conv's epilogue delivers the per-64-row-block channel
+// statistics, the GroupNorm skips its own statistics pass.  Y = conv output, Yn = normalised output.
+extern "C" int sd_op_conv3x3_groupnorm(void* stream, const void* X, const void* W, const float* bias, const float* bias2,
+                                       const void* R, void* Y, int B, int Hin, int Win, int Cin, int Cout,
+                                       const float* gamma, const float* beta, void* Yn, int groups, float eps, int silu) {
+    if (ensure_zero_page()) return -2;
+    const int HW = Hin * Win;
+    SD_REQUIRE(HW % 64 == 0 && !sd_groupnorm_uses_small(B, HW, Cout, 0, groups),
+               "sd_op_conv3x3_groupnorm: %dx%d x %d channels runs the single-launch GroupNorm (no producer statistics)", Hin, Win, Cout);
+    const size_t stats_bytes = (size_t)B * (HW / 64) * Cout * 2 * 4;
+    char* scratch = (char*)op_scratch(stats_bytes + sd_groupnorm_scratch_bytes(B, HW, groups));
+    SD_REQUIRE(scratch, "sd_op_conv3x3_groupnorm: cannot allocate scratch");
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = Cout;
+    a.C = (bf16_t*)Y; a.ldc = Cout; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = 1; a.up = 0; a.Hout = Hin; a.Wout = Win;
+    a.M = B * HW; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page; a.splitk = 1;
+    a.stats = (float*)scratch;
+    if (int rc = sd_launch_conv3x3(a, (hipStream_t)stream)) return rc;
+    GroupNormArgs g;
+    g.x1 = (const bf16_t*)Y; g.C1 = Cout; g.gamma = gamma; g.beta = beta; g.y = (bf16_t*)Yn; g.B = B; g.HW = HW;
+    g.groups = groups; g.eps = eps; g.silu = silu; g.nsplit = sd_groupnorm_nsplit(B, HW);
+    g.partial = (float*)(scratch + stats_bytes);
+    g.stats1 = (const float*)scratch;
+    return sd_launch_groupnorm(g, (hipStream_t)stream);
 }
 
 extern "C" int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows,

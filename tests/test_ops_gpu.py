@@ -171,6 +171,39 @@ def test_groupnorm(sdlib, B, HW, C1, C2, silu, eps):
     assert rel_l2(out, ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [
+    (2, 64, 128, 320),     # LDS-halo conv, two channel tiles
+    (3, 32, 192, 640),     # halo conv, 16 blocks of 64 pixels per sample
+    (1, 32, 320, 1280),    # 40 channels per group (16x16 and below run the single-launch GroupNorm: no statistics)
+    (1, 32, 64, 256),      # 8 channels per group, Cout tail in the second channel tile
+])
+def test_conv3x3_groupnorm_producer_statistics(sdlib, B, H, Cin, Cout):
+    """The plan's conv -> GroupNorm pair: statistics come from the conv epilogue (sums of the bf16-rounded outputs)."""
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b, b2 = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    r = r16(torch.randn(B, Cout, H, H, generator=g))
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    conv = r16(F.conv2d(x, w, b, padding=1) + b2[None, :, None, None] + r)
+    ref = F.silu(F.group_norm(conv, 32, gamma, beta, 1e-5))
+    xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    wd = dev(w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin // 64, 64).permute(0, 2, 1, 3).contiguous(), torch.bfloat16)
+    rd = dev(r.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    y = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    yn = torch.full_like(y, float("nan"))
+    _lib.check(sdlib.sd_op_conv3x3_groupnorm(stream(), P(xd), P(wd), P(b), P(b2), P(rd), P(y), B, H, H, Cin, Cout,
+                                             P(gamma), P(beta), P(yn), 32, 1e-5, 1))
+    torch.cuda.synchronize()
+    assert rel_l2(y.permute(0, 3, 1, 2), conv) < TOL
+    assert rel_l2(yn.permute(0, 3, 1, 2), ref) < TOL
+    # and the same GroupNorm computing its own statistics from the stored tensor agrees to rounding
+    own = torch.full_like(y, float("nan"))
+    _lib.check(sdlib.sd_op_groupnorm(stream(), P(y), Cout, None, 0, P(gamma), P(beta), P(own), B, H * H, 32, 1e-5, 1))
+    torch.cuda.synchronize()
+    assert rel_l2(yn, own) < 2e-3
+
+
 @pytest.mark.parametrize("rows,C", [(300, 320), (77, 640), (1024, 1280)])
 def test_layernorm(sdlib, rows, C):
     g = torch.Generator().manual_seed(rows)
