@@ -202,6 +202,18 @@ int sd_op_time_embedding(void* stream, float t, const void* W1, const float* b1,
  * which an MFMA accumulator tile is consumed as the next product's operand).  Both are passed TILED so that every
  * LDS-DMA piece of the kernel is one contiguous KiB: At [samples][C/32][640][32], Bw [samples][C/32][20][32][32] (bf16).
  * sd_unet_set_context builds both from the prompt.  M tokens, rows_per_sample tokens per sample (multiple of 128). */
+/* LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock norm1 -> attn1 q|k|v, norm3 -> ff GEGLU; diffusers
+ * attention.py, reached from src/models.py:227).  The producer of the residual stream leaves per-row (sum, sum of squares)
+ * partials of its stored bf16 output, [parts][M][2] fp32 (sd_op_ln_partials: kind 0 = a GEMM with N columns, kind 1 = the
+ * fused cross-attention of M rows x N channels); the consumer runs on the UN-normalised rows with Wg = bf16(W * gamma),
+ * c1[n] = sum_k Wg[n][k], c2[n] = sum_k W[n][k] beta[k] + b[n] and finishes  rstd_m (acc - mean_m c1[n]) + c2[n]. */
+int sd_op_ln_partials(int kind, int M, int N);
+int sd_op_gemm_rowstats(void* stream, const void* X, long long ldx, const void* W, const float* bias, const void* R,
+                        long long ldr, void* C, long long ldc, int M, int N, int K, float* rowstats);
+int sd_op_gemm_ln(void* stream, const void* X, long long ldx, const void* Wg, const float* c1, const float* c2,
+                  const float* rowstats, int parts, float eps, void* C, long long ldc, int M, int N, int K, int epi);
+int sd_op_xattn_fused_rowstats(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                               const float* bias, int M, int C, int rows_per_sample, int L, float* rowstats);
 int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                       const float* bias, int M, int C, int rows_per_sample, int L);
 

@@ -132,6 +132,34 @@ __device__ __forceinline__ void tile_channel_stats(const f32x4 (&acc)[TN][TM], f
     }
 }
 
+// LayerNorm statistics of an output tile for the GEMM that consumes the rows un-normalised (GemmArgs::ln_rs): per row
+// the sum and sum of squares of this wave's bf16-rounded outputs (TN 16-column tiles) -> part[m][2]; rows_of_wave = 16 TM.
+template <int TN, int TM>
+__device__ __forceinline__ void tile_row_stats(const f32x4 (&acc)[TN][TM], float* __restrict__ part, int n_base, int N,
+                                               int m_base, int M, int lane) {
+    const int lrow = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const bool live = n_base + a * 16 + lq * 4 < N;
+            const unsigned p0 = pack2bf(acc[a][b][0], acc[a][b][1]), p1 = pack2bf(acc[a][b][2], acc[a][b][3]);
+            const float v[4] = {bflo(p0), bfhi(p0), bflo(p1), bfhi(p1)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = live ? v[j] : 0.f;
+                s += x;
+                q = __builtin_fmaf(x, x, q);
+            }
+        }
+        s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        const int m = m_base + b * 16 + lrow;
+        if (lq == 0 && m < M) *(f32x2_t*)(part + (long)m * 2) = f32x2_t{s, q};
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, hb);
             issue_w(s_begin * 9, Wb + wst * WBYTES);
             issue_w(s_begin * 9 + 1, Wb + (wst == 2 ? 0 : wst + 1) * WBYTES);
-            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N) && !p.stats;
+            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N);
         }
 
         // ---- epilogue, phase B: stores only ----------------------------------------------------------------

@@ -231,6 +231,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
     };
 
+    // LayerNorm fold (consumer side): lane l owns row l of this wave's 64 rows and fetches that row's partials.
+    //  * std epilogue (registers to spare): all partials are requested under the first K tile (ordinary loads older than
+    //    every later LDS-DMA: retired in order long before the epilogue) -> no latency left in the epilogue;
+    //  * GEGLU (the 256 x 256 tile has no register to spare): four partials at a time in the epilogue, the first four
+    //    together with the c1 / bias vectors.
+    constexpr bool LN_OK = (EPI == EPI_STD || EPI == EPI_GEGLU) && AMODE == AMODE_GEMM && WTM == 64 && !DT && STAGES == 2;
+    constexpr bool LN_PRE = LN_OK && EPI == EPI_STD;
+    constexpr int LN_MAXP = 16;
+    char* lnbuf = smem + STAGES * STAGE_BYTES + wave * 512;
+    // c1 | c2 of this N-wave's WTN columns, fetched by LDS-DMA under the first K tile (waves wm == 0; the K loop's own
+    // wait + barrier publish them): the epilogue of a folded GEMM then has no global load at all
+    char* lnvec = smem + STAGES * STAGE_BYTES + NW * 512 + (wave / WAVES_M) * (2 * WTN * 4);
+    f32x2_t lnp[LN_PRE ? LN_MAXP : 4];
+    auto ln_vec_dma = [&]() {
+        if (wave % WAVES_M == 0 && lane < WTN / 4) {
+            const int n = min(n0 + (wave / WAVES_M) * WTN + lane * 4, p.N - 4);
+            glds16(p.ln_c1 + n, lnvec);
+            glds16(p.bias + n, lnvec + WTN * 4);
+        }
+    };
+    auto ln_issue = [&](int i0, int cnt) {           // partials i0 .. i0 + cnt - 1 of this lane's row -> lnp[0 ..]
+        const int mrow = min(m0 + wm * WTM + lane, p.M - 1);
+        const float* src = p.ln_rs + (long)mrow * 2;
+        // unconditional loads from a clamped index (a select on a loaded value makes hipcc branch around the load and
+        // wait for it at the join: sixteen serial round trips); absent partials are masked when they are summed
+#pragma unroll
+        for (int i = 0; i < (LN_OK ? LN_MAXP : 0); ++i)
+            if (i < cnt) lnp[i] = *(const f32x2_t*)(src + (long)min(i0 + i, p.ln_np - 1) * p.M * 2);
+    };
+
     if (work >= nwork) return;
     decode(work);
     setup();
@@ -275,6 +305,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             load_frags(sb, 0, xf0, wf0);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < KT) stage(kt_begin + kt + 1, (g + kt + 1) & 1);
+            if (LN_OK && kt == 0 && p.ln_rs) {
+                if (LN_PRE) ln_issue(0, LN_MAXP);
+                ln_vec_dma();
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (FRAG_DB) {
                 load_frags(sb, 1, xf1, wf1);
@@ -327,6 +361,52 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             for (int b = 0; b < TM; ++b) acc[a][b] *= sv;
         }
     }
+    if (LN_OK && p.ln_rs) {
+        // LayerNorm fold: rstd * (acc - mean * c1[n]) + c2[n]  (c2 = W beta + b arrives as p.bias)
+        if (!LN_PRE) ln_issue(0, 4);
+        constexpr int TNH = LN_PRE ? TN : (TN + 1) / 2;      // c1 / c2 vectors in flight at a time
+        f32x4 cv[TNH], bv[TNH];
+        auto vec_load = [&](int a0) {
+#pragma unroll
+            for (int a = 0; a < TNH; ++a) {
+                cv[a] = *(const f32x4*)(lnvec + ((a0 + a) * 16 + lq * 4) * 4);
+                bv[a] = *(const f32x4*)(lnvec + WTN * 4 + ((a0 + a) * 16 + lq * 4) * 4);
+            }
+        };
+        vec_load(0);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < (LN_PRE ? LN_MAXP : 4); ++i) {
+            s += i < p.ln_np ? lnp[i][0] : 0.f;
+            q += i < p.ln_np ? lnp[i][1] : 0.f;
+        }
+        if (!LN_PRE) {
+            for (int i0 = 4; i0 < p.ln_np; i0 += 4) {
+                ln_issue(i0, 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s += i0 + i < p.ln_np ? lnp[i][0] : 0.f;
+                    q += i0 + i < p.ln_np ? lnp[i][1] : 0.f;
+                }
+            }
+        }
+        const float invk = 1.0f / (float)p.K;
+        const float mean = s * invk;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(q * invk - mean * mean, 0.f) + p.ln_eps);
+        *(f32x2_t*)(lnbuf + lane * 8) = f32x2_t{mean, rstd};      // row = lane; every lane needs rows b * 16 + lrow
+        f32x2_t mr[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + (b * 16 + lrow) * 8);
+#pragma unroll
+        for (int a0 = 0; a0 < TN; a0 += TNH) {
+            if (a0 > 0) vec_load(a0);
+#pragma unroll
+            for (int a = 0; a < TNH; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    if (a0 + a < TN) acc[a0 + a][b] = (acc[a0 + a][b] - cv[a] * mr[b][0]) * mr[b][1] + bv[a];
+        }
+    }
     if (p.splitk == 1) {
         if (EPI == EPI_STD && p.R) {
             // all residual loads of the tile issued back to back (rows clamped instead of branched, so
@@ -349,7 +429,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                     acc[a][b][2] += bflo(rr[a][b][1]); acc[a][b][3] += bfhi(rr[a][b][1]);
                 }
         }
-        if (p.bias) {
+        if (p.bias && !(LN_OK && p.ln_rs)) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 // (GEGLU keeps the packed [16 value | 16 gate] column order for its bias)
@@ -405,7 +485,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             primed = true;
             // phase B issues exactly EPI_STORES stores per wave iff the finished tile is full
             stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && (p.ldc & 7) == 0 && p.splitk == 1 &&
-                             !(p.tune & (32 | 64 | 8)) && !p.out_fp8 && !p.stats;
+                             !(p.tune & (32 | 64 | 8)) && !p.out_fp8;   // (statistics stores come before them: only more to wait for)
         }
     }
 
@@ -428,6 +508,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         // GroupNorm statistics of this tile for the consuming GroupNorm (64-row blocks = this wave's rows; WTM == 64)
         if (EPI == EPI_STD && WTM == 64 && p.stats)
             tile_channel_stats<TN, TM>(acc, p.stats, (em0 + wm * WTM) >> 6, p.N, en0 + wn * WTN, p.N, em0 + wm * WTM, p.M, lane);
+        if (EPI == EPI_STD && p.rowstats)
+            tile_row_stats<TN, TM>(acc, p.rowstats + ((long)(en0 / BN) * WAVES_N + wn) * p.M * 2, en0 + wn * WTN, p.N,
+                                   em0 + wm * WTM, p.M, lane);
         // Stores are issue-bound (one 8-B store per lane per 16x16 tile): v_permlane16_swap pairs two
         // adjacent tiles so that every lane owns 16 contiguous bytes -> half the store instructions,
         // 64 contiguous bytes per row per instruction.  After the swap lane group lq holds
@@ -559,7 +642,9 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
     static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
     a.tune = tune;
-    constexpr int smem = STAGES * (BM + BN) * 128;
+    // + 512 B per wave: (mean, rstd) slots of the LayerNorm fold (2-stage bf16 kernels)
+    // + (c1 | c2) of the tile's BN columns
+    constexpr int smem = STAGES * (BM + BN) * 128 + (STAGES == 2 && DT == 0 ? WAVES_M * WAVES_N * 512 + 2 * BN * 4 : 0);
     static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, AMODE, EPI, DT>;
     static bool attr_set = false;
@@ -625,9 +710,17 @@ static int check_stats(const GemmArgs& a, int epi) {
                "producer statistics: plain epilogue, M %% 64 == 0 and no split-K (M=%d splitk=%d)", a.M, a.splitk);
     return 0;
 }
+static int check_ln(const GemmArgs& a, int epi) {
+    if (a.rowstats) SD_REQUIRE(epi == EPI_STD && !(a.splitk > 1 && a.slab), "LayerNorm partials: plain epilogue without split-K");
+    if (!a.ln_rs) return 0;
+    SD_REQUIRE((epi == EPI_STD || epi == EPI_GEGLU) && a.dt == 0 && !(a.splitk > 1 && a.slab) && a.ln_c1 && a.ln_np > 0 &&
+               a.ln_np <= 16 && a.X2 == nullptr && a.K1 == a.K && a.K >= 128 && big_tile_mode() == 0 && a.bias && !a.R && !a.bias2,
+               "LayerNorm fold: bf16 operands, std / GEGLU epilogue, one K segment, no split-K (epi=%d np=%d)", epi, a.ln_np);
+    return 0;
+}
 
 int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
-    if (check_stats(a, epi)) return -1;
+    if (check_stats(a, epi) || check_ln(a, epi)) return -1;
     if (a.dt == 1) {
         if (check_fp8(a, "gemm")) return -1;
         SD_REQUIRE(a.N % 4 == 0 && a.M > 0 && a.N > 0 && a.zero_page, "gemm fp8: bad problem");

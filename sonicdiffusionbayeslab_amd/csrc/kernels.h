@@ -35,6 +35,16 @@ struct GemmArgs {
     // GroupNorm statistics of the output from this kernel's epilogue (split-K = 1 only): [M / 64][N][2] fp32 partial
     // sums / sums of squares per 64-row block and channel (common.h::tile_channel_stats); null = off
     float* stats = nullptr;
+    // LayerNorm folded into the consuming GEMM.  PRODUCER side (std epilogue, split-K = 1): rowstats = [2 tiles_n][M][2]
+    // fp32, per row the (sum, sum of squares) of every N-wave's 80 output columns (common.h::tile_row_stats).
+    // CONSUMER side: X holds the un-normalised rows, W = bf16(W * gamma), ln_c1[n] = sum_k W'[n][k], bias = W beta + b;
+    // the epilogue turns the raw sums into  rstd_m * (acc - mean_m * c1[n]) + bias[n]  with mean / rstd of row m
+    // from its ln_np partials ln_rs[part][M][2] (K = the normalised width).
+    float* rowstats = nullptr;
+    const float* ln_rs = nullptr;
+    const float* ln_c1 = nullptr;
+    int ln_np = 0;
+    float ln_eps = 1e-5f;
     // fp8-e4m3 operands (dt = 1): X and W hold OCP e4m3 bytes, K (and ldx / ldw / Cin) count fp8 elements and are
     // multiples of 128; the epilogue multiplies the fp32 sums by wscale[n] * xscale_inv before bias / residual.
     int dt = 0;
@@ -122,9 +132,11 @@ struct XattnArgs {
     const bf16_t* Bw = nullptr;   // [samples][C/32][20][32][32]: (channel tile, 32-slot slice, channel, slot in PERMUTED k order)
     const float* bias = nullptr;  // [C] to_out bias
     int M = 0, C = 0, rows_per_sample = 0, L = 0;
+    float* rowstats = nullptr;    // [2 * channel slices][M][2]: LayerNorm partials of Y (GemmArgs::rowstats layout), null = off
     unsigned long long* stamps = nullptr;   // diagnostic: 8 s_memtime stamps per workgroup (SD_XATTN_STAMPS), else null
 };
 bool sd_xattn_fused_applicable(int rows_per_sample, int C, int heads, int L);
+int sd_xattn_slices(int M, int C);     // channel slices of the launch (LayerNorm partials per row = 2 * slices)
 int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream);
 int sd_launch_xattn_expand(const bf16_t* kv, bf16_t* out, int B, int L, int C, int NH, int col_off, float scale,
                            hipStream_t stream);

@@ -112,6 +112,10 @@ struct Op {
     // GroupNorm statistics from the producer's epilogue: `stats` = tensor this op writes ([M/64][N][2] fp32),
     // s1 / s2 = the statistics tensors of a GroupNorm's sources (it then skips its statistics pass)
     int stats = -1, s1 = -1, s2 = -1;
+    // LayerNorm fold: rs = row partials this op writes ([np][M][2] fp32); lnrs / lnnp / c1 = partials and column sums
+    // this GEMM normalises with (its x1 is the un-normalised tensor, its weights carry gamma, its bias W beta + b)
+    int rs = -1, lnrs = -1, lnnp = 0;
+    size_t c1 = NOFF;
     size_t wsc = NOFF;
     float xs = 1.f, os = 1.f;
     int nwrap = 0;
@@ -458,6 +462,33 @@ struct Packer {
         for (auto& n : names)
             for (float v : P(n)) *o++ = f32_to_bf16_host(v);
     }
+    // LayerNorm folded into the GEMM that consumes it (GemmArgs::ln_rs): rows [N][K] fp32 -> key.ln = bf16(W * gamma),
+    // key.c1[n] = sum_k of the ROUNDED row (what the kernel's raw sums contain per unit of the row mean),
+    // key.c2[n] = sum_k W[n][k] beta[k] + bias[n]
+    void ln_fold(const std::string& key, const float* w, int N, int K, const std::vector<float>& gamma,
+                 const std::vector<float>& beta, const float* bias) {
+        const size_t woff = alloc(key + ".ln", (size_t)N * K * 2);
+        const size_t c1off = alloc(key + ".c1", (size_t)N * 4);
+        const size_t c2off = alloc(key + ".c2", (size_t)N * 4);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + woff);
+        float* c1 = (float*)(u->hblob.data() + c1off);
+        float* c2 = (float*)(u->hblob.data() + c2off);
+        for (int n = 0; n < N; ++n) {
+            double s1 = 0.0, s2 = bias ? (double)bias[n] : 0.0;
+            for (int k = 0; k < K; ++k) {
+                const float wv = w[(size_t)n * K + k];
+                const unsigned short r = f32_to_bf16_host(wv * gamma[k]);
+                o[(size_t)n * K + k] = r;
+                const unsigned bits = (unsigned)r << 16;
+                float rf;
+                memcpy(&rf, &bits, 4);
+                s1 += rf;
+                s2 += (double)wv * beta[k];
+            }
+            c1[n] = (float)s1;
+            c2[n] = (float)s2;
+        }
+    }
     void geglu(const std::string& t, int C) {  // rows: every 32 = [16 value | 16 gate]
         const auto& w = P(t + "ff.net.0.proj.weight");
         const auto& b = P(t + "ff.net.0.proj.bias");
@@ -479,6 +510,16 @@ struct Packer {
         }
         (void)bo;
         if (u->fp8) quant_rows(t + "ff.geglu.weight", perm.data(), 2 * H, C, (C + 127) / 128 * 128);
+        else {      // norm3 folded in: same packed row order
+            std::vector<float> pw((size_t)2 * H * C), pb(2 * H);
+            for (int r = 0; r < 2 * H; ++r) {
+                const int grp = r / 32, within = r % 32;
+                const int src = within < 16 ? grp * 16 + within : H + grp * 16 + (within - 16);
+                memcpy(&pw[(size_t)r * C], &w[(size_t)src * C], (size_t)C * 4);
+                pb[r] = b[src];
+            }
+            ln_fold(t + "ff.geglu.weight", pw.data(), 2 * H, C, P(t + "norm3.weight"), P(t + "norm3.bias"), pb.data());
+        }
     }
     void resnet(const std::string& p, int cin, int cout) {
         f32(p + "norm1.weight"); f32(p + "norm1.bias");
@@ -501,6 +542,12 @@ struct Packer {
         } else {
             bf16_same(p + "proj_in.weight");
             concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"});
+            {   // norm1 folded into the q|k|v projection
+                std::vector<float> all;
+                for (const char* n : {"attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight"})
+                    all.insert(all.end(), P(t + n).begin(), P(t + n).end());
+                ln_fold(t + "attn1.qkv.weight", all.data(), 3 * c, c, P(t + "norm1.weight"), P(t + "norm1.bias"), nullptr);
+            }
             bf16_same(t + "ff.net.2.weight");
         }
         bf16_same(t + "attn1.to_out.0.weight"); f32(t + "attn1.to_out.0.bias");
@@ -686,6 +733,27 @@ struct Builder {
         stats_of[o.out] = o.stats;
     }
 
+    // SD_LN_FOLD=0: every LayerNorm is its own launch (round-1 behaviour)
+    bool ln_fold = !(getenv("SD_LN_FOLD") && atoi(getenv("SD_LN_FOLD")) == 0);
+    // Ask the op that produced a residual-stream tensor for per-row LayerNorm partials; returns the partial count (0 =
+    // this producer cannot deliver them: split-K, fp8 output, ...) and the tensor in `rs`.
+    int want_rowstats(Op& o, int M, int C, int& rs) {
+        int np = 0;
+        if (o.kind == OP_GEMM && o.epi == 0 && o.splitk == 1 && !o.out_fp8 && o.N == C && o.M == M && o.ldc_o == 0) np = (C + 159) / 160 * 2;
+        else if (o.kind == OP_XATTN && o.N == C && o.M == M) np = 2 * sd_xattn_slices(M, C);
+        if (!ln_fold || np == 0) return 0;
+        o.rs = rs = tensor((size_t)np * M * 2 * 4);
+        return np;
+    }
+    // GEMM over the un-normalised rows x with the LayerNorm folded in (weights key.ln / key.c1 / key.c2 of the packer)
+    int gemm_ln(int x, int rs, int np, int M, int N, int C, const std::string& w, int epi) {
+        Op o; o.kind = OP_GEMM; o.x1 = x; o.K1 = o.K = o.Kalg = C; o.M = M; o.N = N; o.epi = epi; o.splitk = 1;
+        o.w = W(w + ".ln"); o.c1 = W(w + ".c1"); o.b = W(w + ".c2"); o.lnrs = rs; o.lnnp = np;
+        o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
+        push(o);
+        return o.out;
+    }
+
     int tensor(size_t bytes, bool persistent = false) {
         Tn t;
         t.bytes = (bytes + 255) / 256 * 256;
@@ -788,8 +856,13 @@ struct Builder {
         const float sn = fq ? u->s_norm : 0.f, sf = fq ? u->s_ff : 0.f;
         int g = gn(x, C, -1, 0, hw, p + "norm.weight", p + "norm.bias", 1e-6f, 0, fq);
         int h0 = gemm(g, C, -1, 0, M, C, p + "proj_in.weight", p + "proj_in.bias", -1, 0, sn);
-        int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias", fq);
-        int qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0, sn);
+        int qkv, rs = -1, np = 0;
+        if (!fq && (np = want_rowstats(pl.ops.back(), M, C, rs)) > 0) {       // norm1 folded into the projection
+            qkv = gemm_ln(h0, rs, np, M, 3 * C, C, t + "attn1.qkv.weight", 0);
+        } else {
+            int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias", fq);
+            qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0, sn);
+        }
         int a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
         int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
@@ -830,8 +903,13 @@ struct Builder {
             int a2 = attn(q2, 0, C, kv, 0, C, 2 * C, hw, L, C);
             h2 = gemm(a2, C, -1, 0, M, C, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", h1, 0);
         }
-        int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias", fq);
-        int ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, sn, sf);
+        int ff;
+        if (!fq && (np = want_rowstats(pl.ops.back(), M, C, rs)) > 0) {       // norm3 folded into the GEGLU projection
+            ff = gemm_ln(h2, rs, np, M, 8 * C, C, t + "ff.geglu.weight", 1);
+        } else {
+            int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias", fq);
+            ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, sn, sf);
+        }
         int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, sf);
         const int out = gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
         if (pl.ops.back().splitk == 1) {          // the block's output feeds the next resnet's GroupNorm
@@ -1037,9 +1115,9 @@ bool wrap_skipped(const Wrap& w, int branch) {
     return w.type == 0 ? w.layer_i >= cache_layer_id : w.layer_i > cache_layer_id;
 }
 
-void op_tensors(const Op& o, int ins[8], int& nin) {
+void op_tensors(const Op& o, int ins[9], int& nin) {
     nin = 0;
-    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt, o.s1, o.s2})
+    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt, o.s1, o.s2, o.lnrs})
         if (t >= 0) ins[nin++] = t;
 }
 
@@ -1055,10 +1133,11 @@ void assign_memory(sd_unet* u, Plan& pl) {
         for (int i = 0; i < nops; ++i) {
             if (pl.ops[i].out >= 0) producer[pl.ops[i].out] = i;
             if (pl.ops[i].stats >= 0) producer[pl.ops[i].stats] = i;
+            if (pl.ops[i].rs >= 0) producer[pl.ops[i].rs] = i;
         }
         for (int i = 0; i < nops; ++i) {
             if (pl.skipped[i]) continue;
-            int ins[8], nin;
+            int ins[9], nin;
             op_tensors(pl.ops[i], ins, nin);
             for (int k = 0; k < nin; ++k) {
                 const int p = producer[ins[k]];
@@ -1071,10 +1150,10 @@ void assign_memory(sd_unet* u, Plan& pl) {
     // lifetimes over the full plan
     for (int i = 0; i < nops; ++i) {
         const Op& o = pl.ops[i];
-        int ins[8], nin;
+        int ins[9], nin;
         op_tensors(o, ins, nin);
         for (int k = 0; k < nin; ++k) pl.tensors[ins[k]].last = std::max(pl.tensors[ins[k]].last, i);
-        for (int t : {o.out, o.aux, o.stats})
+        for (int t : {o.out, o.aux, o.stats, o.rs})
             if (t >= 0) {
                 if (pl.tensors[t].def < 0) pl.tensors[t].def = i;
                 pl.tensors[t].last = std::max(pl.tensors[t].last, i);
@@ -1183,6 +1262,8 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
             if (o.out_fp8) { a.out_fp8 = 1; a.oscale = o.os; a.ldc = o.Cpad; }
             a.stats = (float*)T(o.stats);
+            a.rowstats = (float*)T(o.rs);
+            if (o.lnrs >= 0) { a.ln_rs = (const float*)T(o.lnrs); a.ln_np = o.lnnp; a.ln_c1 = (const float*)(wb + o.c1); a.ln_eps = 1e-5f; }
             return sd_launch_gemm(a, o.epi, stream);
         }
         case OP_LN:
@@ -1207,6 +1288,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.X = (const bf16_t*)T(o.x1); a.R = (const bf16_t*)T(o.r); a.Y = (bf16_t*)T(o.out);
             a.At = (const bf16_t*)T(o.wt); a.Bw = (const bf16_t*)T(o.x2); a.bias = (const float*)(wb + o.b);
             a.M = o.M; a.C = o.N; a.rows_per_sample = o.rpb; a.L = o.sm_valid;
+            a.rowstats = (float*)T(o.rs);
             return sd_launch_xattn_fused(a, stream);
         }
         case OP_CLIP_EMBED:
@@ -1762,6 +1844,41 @@ extern "C" int sd_op_quantize_fp8(void* stream, const void* x_bf16, void* y_fp8,
 }
 
 // ---- fused prompt cross-attention, operator level: Y = R + sum_h softmax_L(X A_h) B_h + b_o (xattn.hip) ----
+// ---- LayerNorm folded into the consuming GEMM (the plan's norm1 -> q|k|v and norm3 -> GEGLU pairs) ----
+// number of per-row partials a producer writes: kind 0 = GEMM with N output columns, kind 1 = fused cross-attention (M, C)
+extern "C" int sd_op_ln_partials(int kind, int M, int N) { return kind == 0 ? (N + 159) / 160 * 2 : 2 * sd_xattn_slices(M, N); }
+// producer: C = X W^T + bias + R, and rowstats[parts][M][2] = per-row (sum, sum of squares) partials of the stored C
+extern "C" int sd_op_gemm_rowstats(void* stream, const void* X, long long ldx, const void* W, const float* bias, const void* R,
+                                   long long ldr, void* C, long long ldc, int M, int N, int K, float* rowstats) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(rowstats, "sd_op_gemm_rowstats: null partials buffer");
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.ldr = ldr;
+    a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page; a.splitk = 1; a.rowstats = rowstats;
+    return sd_launch_gemm(a, 0, (hipStream_t)stream);
+}
+// consumer: C = epi(LayerNorm(X) W^T + b) computed from the UN-normalised X: Wg = bf16(W * gamma), c1[n] = sum_k Wg[n][k],
+// c2[n] = sum_k W[n][k] beta[k] + b[n]; mean / rstd of a row from its `parts` partials.  epi 0 = plain, 1 = GEGLU.
+extern "C" int sd_op_gemm_ln(void* stream, const void* X, long long ldx, const void* Wg, const float* c1, const float* c2,
+                             const float* rowstats, int parts, float eps, void* C, long long ldc, int M, int N, int K, int epi) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(epi == 0 || epi == 1, "sd_op_gemm_ln: epi %d (0 = plain, 1 = GEGLU)", epi);
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)Wg; a.bias = c2;
+    a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page; a.splitk = 1;
+    a.ln_rs = rowstats; a.ln_np = parts; a.ln_c1 = c1; a.ln_eps = eps;
+    return sd_launch_gemm(a, epi, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_xattn_fused_rowstats(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                                          const float* bias, int M, int C, int rows_per_sample, int L, float* rowstats) {
+    SD_REQUIRE(sd_xattn_fused_applicable(rows_per_sample, C, 8, L), "sd_op_xattn_fused_rowstats: shape not supported");
+    XattnArgs a;
+    a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
+    a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L; a.rowstats = rowstats;
+    return sd_launch_xattn_fused(a, (hipStream_t)stream);
+}
+
 extern "C" int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                                  const float* bias, int M, int C, int rows_per_sample, int L) {
     SD_REQUIRE(sd_xattn_fused_applicable(rows_per_sample, C, 8, L) || getenv("SD_XATTN_FUSED"),

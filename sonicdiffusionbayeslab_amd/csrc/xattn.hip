@@ -277,6 +277,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     const int brow = hg * (32 * HKEYS * 2);                     // this wave's tile inside a stage
     const int NS = 2 * NP;
     f32x16 acc;
+    float ysum = 0.f, ysq = 0.f;      // LayerNorm partials of this lane's token over its channels (p.rowstats)
     int st = 0;
     for (int s = 0; s < NS; ++s) {
         const int pi = pbeg + (s >> 1), kh = s & 1;
@@ -343,6 +344,11 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
                 const float y0 = acc[4 * g + 0] + bv[0] + bflo(rr[0]), y1 = acc[4 * g + 1] + bv[1] + bfhi(rr[0]);
                 const float y2 = acc[4 * g + 2] + bv[2] + bflo(rr[1]), y3 = acc[4 * g + 3] + bv[3] + bfhi(rr[1]);
                 pk[g] = u32x2{pack2bf(y0, y1), pack2bf(y2, y3)};
+                if (p.rowstats) {
+                    const float v0 = bflo(pk[g][0]), v1 = bfhi(pk[g][0]), v2 = bflo(pk[g][1]), v3 = bfhi(pk[g][1]);
+                    ysum += (v0 + v1) + (v2 + v3);
+                    ysq = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, ysq))));
+                }
             }
             // lanes r / r + 32 hold channels 8 g + (0..3) / 8 g + (4..7): swap pairs of groups -> 16 contiguous bytes per lane
 #pragma unroll
@@ -356,6 +362,11 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
         }
         st = st == 2 ? 0 : st + 1;
     }
+    if (p.rowstats) {       // partial (channel slice, tile parity hg): the two lane halves hold channels 4 h + (0..3) of every 8
+        ysum += __shfl_xor(ysum, 32);
+        ysq += __shfl_xor(ysq, 32);
+        if (h == 0) *(f32x2_t*)(p.rowstats + (((long)blockIdx.y * 2 + hg) * p.M + trow) * 2) = f32x2_t{ysum, ysq};
+    }
     stamp(5);
 }
 
@@ -365,6 +376,16 @@ bool sd_xattn_fused_applicable(int rows_per_sample, int C, int heads, int L) {
     static const char* env = getenv("SD_XATTN_FUSED");
     if (env && atoi(env) == 0) return false;
     return heads == 8 && L > 64 && L <= 80 && C % 64 == 0 && C >= 128 && C <= MAXC && rows_per_sample % TOK == 0;
+}
+
+// channel slices (each repeats phase 1): only when the token grid leaves most of the 256 CUs idle
+int sd_xattn_slices(int M, int C) {
+    static const int force = getenv("SD_XATTN_SLICES") ? atoi(getenv("SD_XATTN_SLICES")) : 0;
+    const int wgs = M / TOK, np = C / 64;
+    int nsl = 1;
+    if (force > 0) nsl = force;
+    else if (wgs <= 128) nsl = 2;
+    return nsl > np ? np : nsl;
 }
 
 int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
@@ -379,13 +400,7 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    // channel slices (each repeats phase 1): only when the token grid leaves most of the 256 CUs idle
-    const int wgs = a.M / TOK, np = a.C / 64;
-    int nsl = 1;
-    static const int force = getenv("SD_XATTN_SLICES") ? atoi(getenv("SD_XATTN_SLICES")) : 0;
-    if (force > 0) nsl = force;
-    else if (wgs <= 128) nsl = 2;
-    if (nsl > np) nsl = np;
+    const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
     hipLaunchKernelGGL(xattn_fused_kernel, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;

@@ -204,6 +204,66 @@ def test_conv3x3_groupnorm_producer_statistics(sdlib, B, H, Cin, Cout):
     assert rel_l2(yn, own) < 2e-3
 
 
+def fold_layernorm(w, gamma, beta, bias):
+    """Host-side packing of a LayerNorm-folded GEMM weight (mirror of the packer's ln_fold in unet.hip)."""
+    wg = r16(w * gamma[None, :])
+    c1 = wg.double().sum(1).float()
+    c2 = (w.double() @ beta.double()).float() + (bias if bias is not None else 0.0)
+    return wg, c1, c2
+
+
+@pytest.mark.parametrize("M,C,N2,epi,mean", [
+    (256, 320, 960, 0, 0.0),       # norm1 -> q|k|v at the 64x64 level's width
+    (192, 640, 5120, 1, 0.5),      # norm3 -> GEGLU (256 x 256 tile), rows with a common offset
+    (128, 1280, 3840, 0, 2.0),     # 16 partials per row, |mean| ~ sigma
+    (320, 320, 2560, 1, 0.0),      # GEGLU, M tail in the 256-row tile
+    (200, 320, 960, 0, 0.0),       # M tail (rows 192..199 of the last 64-row block)
+])
+def test_layernorm_folded_into_gemm(sdlib, M, C, N2, epi, mean):
+    """h = X W1^T + b1 + R with per-row partials from the epilogue, then Y = epi(LN(h) W2^T + b2) computed by the GEMM on the
+    un-normalised h (diffusers BasicTransformerBlock norm1 -> attn1 / norm3 -> ff): against LayerNorm + linear in fp32."""
+    g = torch.Generator().manual_seed(M + C + N2)
+    x = r16(torch.randn(M, C, generator=g))
+    w1 = r16(torch.randn(C, C, generator=g) / math.sqrt(C))
+    b1 = torch.randn(C, generator=g) + mean
+    r = r16(torch.randn(M, C, generator=g) * 2)
+    r[:, 7] += 12.0                                   # an outlier channel, as the SD residual stream has
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w2 = torch.randn(N2, C, generator=g) / math.sqrt(C)
+    b2 = torch.randn(N2, generator=g)
+    h = r16(x @ w1.t() + b1 + r)
+    z = F.layer_norm(h, (C,), gamma, beta, 1e-5) @ r16(w2).t() + b2
+    if epi:
+        H = N2 // 2
+        ref = z[:, :H] * F.gelu(z[:, H:])
+        idx = torch.tensor([(q // 32) * 16 + q % 32 if q % 32 < 16 else H + (q // 32) * 16 + q % 32 - 16 for q in range(N2)])
+        w2p, b2p = w2[idx], b2[idx]
+    else:
+        ref, w2p, b2p = z, w2, b2
+    wg, c1, c2 = fold_layernorm(w2p, gamma, beta, b2p)
+    parts = sdlib.sd_op_ln_partials(0, M, C)
+    assert parts == 2 * ((C + 159) // 160)
+    hd = torch.full((M, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    rs = torch.full((parts, M, 2), float("nan"), device="cuda")
+    _lib.check(sdlib.sd_op_gemm_rowstats(stream(), P(x, torch.bfloat16), C, P(w1, torch.bfloat16), P(b1), P(r, torch.bfloat16), C,
+                                         P(hd), C, M, C, C, P(rs)))
+    torch.cuda.synchronize()
+    assert rel_l2(hd, h) < TOL
+    tot, h64 = rs.sum(0).cpu().double(), hd.double().cpu()
+    assert torch.allclose(tot[:, 0], h64.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, 1], (h64 * h64).sum(1), rtol=1e-4, atol=1e-2)
+    No = N2 // 2 if epi else N2
+    out = torch.full((M, No), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_gemm_ln(stream(), P(hd), C, P(wg, torch.bfloat16), P(c1), P(c2), P(rs), parts, 1e-5,
+                                   P(out), No, M, N2, C, epi))
+    torch.cuda.synchronize()
+    # reference from the device's own h (the fold is judged, not the producer's rounding)
+    hh = hd.float().cpu()
+    z = F.layer_norm(hh, (C,), gamma, beta, 1e-5) @ r16(w2).t() + b2
+    ref = z[:, :N2 // 2] * F.gelu(z[:, N2 // 2:]) if epi else z
+    assert rel_l2(out, ref) < TOL
+
+
 @pytest.mark.parametrize("rows,C", [(300, 320), (77, 640), (1024, 1280)])
 def test_layernorm(sdlib, rows, C):
     g = torch.Generator().manual_seed(rows)
@@ -402,3 +462,15 @@ def test_xattn_fused(sdlib, B, hw, C, spike):
     print(f"xattn fused B={B} hw={hw} C={C}: vs folded fp32 {e1:.3e}, vs SDPA + linears {e2:.3e}")
     assert torch.isfinite(out.float()).all()
     assert e1 < 8e-3 and e2 < 2e-2
+    # the same launch also delivers the LayerNorm partials of its stored rows (norm3 folded into the GEGLU projection)
+    parts = sdlib.sd_op_ln_partials(1, M, C)
+    rs = torch.full((parts, M, 2), float("nan"), device="cuda")
+    out2 = torch.full_like(out, float("nan"))
+    _lib.check(sdlib.sd_op_xattn_fused_rowstats(stream(), P(x, torch.bfloat16), P(r, torch.bfloat16), P(out2), P(At_t, torch.bfloat16),
+                                                P(Bw_t, torch.bfloat16), P(bo), M, C, hw, L, P(rs)))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    tot = rs.sum(0).cpu()
+    o64 = out.double().cpu()
+    assert torch.allclose(tot[:, 0].double(), o64.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[:, 1].double(), (o64 * o64).sum(1), rtol=1e-4, atol=1e-2)

@@ -46,6 +46,34 @@ def main():
                                                       out.data_ptr(), out.shape[1], M, N, K, epi))
                 ms = timeit(f)
                 print(f"gemm {tag:6s} M={M:6d} N={N:5d} K={K:5d}  {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF/s")
+    if "lnfold" in args.only:
+        print("== LayerNorm fold: producer with row partials / consumer with the fold, against the plain GEMMs + LayerNorm ==")
+        for (hw, C) in ((4096, 320), (1024, 640), (256, 1280)):
+            M = UB * hw
+            x, w, r = rnd(M, C), rnd(C, C), rnd(M, C)
+            bias = torch.randn(C, device="cuda")
+            h = torch.empty(M, C, device="cuda", dtype=bf)
+            parts = lib.sd_op_ln_partials(0, M, C)
+            rs = torch.zeros(parts, M, 2, device="cuda")
+            f0 = lambda: _lib.check(lib.sd_op_gemm(st, x.data_ptr(), C, None, 0, C, w.data_ptr(), bias.data_ptr(), None, r.data_ptr(), C,
+                                                   h.data_ptr(), C, M, C, C, 0))
+            f1 = lambda: _lib.check(lib.sd_op_gemm_rowstats(st, x.data_ptr(), C, w.data_ptr(), bias.data_ptr(), r.data_ptr(), C,
+                                                            h.data_ptr(), C, M, C, C, rs.data_ptr()))
+            t0, t1 = timeit(f0), timeit(f1)
+            print(f"producer proj M={M:6d} C={C:5d}: plain {t0*1e3:7.1f} us   + row partials {t1*1e3:7.1f} us")
+            g, b = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+            n = torch.empty(M, C, device="cuda", dtype=bf)
+            tl = timeit(lambda: _lib.check(lib.sd_op_layernorm(st, h.data_ptr(), g.data_ptr(), b.data_ptr(), n.data_ptr(), M, C, 1e-5)))
+            for (N, epi, tag) in ((3 * C, 0, "qkv"), (8 * C, 1, "geglu")):
+                w2 = rnd(N, C)
+                c1, c2 = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+                out = torch.empty(M, N // 2 if epi else N, device="cuda", dtype=bf)
+                f0 = lambda: _lib.check(lib.sd_op_gemm(st, n.data_ptr(), C, None, 0, C, w2.data_ptr(), c2.data_ptr() if epi else None, None, None, 0,
+                                                       out.data_ptr(), out.shape[1], M, N, C, epi))
+                f1 = lambda: _lib.check(lib.sd_op_gemm_ln(st, h.data_ptr(), C, w2.data_ptr(), c1.data_ptr(), c2.data_ptr(), rs.data_ptr(), parts,
+                                                          1e-5, out.data_ptr(), out.shape[1], M, N, C, epi))
+                t0, t1 = timeit(f0), timeit(f1)
+                print(f"consumer {tag:5s} M={M:6d} N={N:5d}: plain {t0*1e3:7.1f} us (+ LayerNorm {tl*1e3:6.1f} us)   folded {t1*1e3:7.1f} us")
     if not args.only or "conv" in args.only:
         print("== conv3x3 ==")
         cshapes = ((64, 320, 320, 1, 0), (64, 640, 320, 1, 0), (64, 960, 320, 1, 0),
