@@ -3,6 +3,7 @@ parameter enumeration, scheduler coefficient math (checked against the oracle's 
 restatement), batch sharding.  No compute call is made (no GPU here)."""
 import ctypes as C
 import math
+import numpy as np
 import os
 
 import pytest
@@ -397,3 +398,26 @@ def test_finalize_packs_weights_on_the_host(dtype):
         got = packed(t + "attn1.qkv.weight.fp8", 960 * 384, torch.uint8).view(960, 384)
         assert same_codes(got[:, :320], wq.to(torch.float8_e4m3fn).view(torch.uint8)) and (got[:, 320:] == 0).all()
     lib.sd_unet_destroy(h)
+
+
+def test_geglu_polynomial_gelu_error_bound():
+    """The GEGLU epilogue's transcendental-free GELU (csrc/common.h::geglu_pair): its constants, evaluated in float32 the
+    way the kernel does, stay within 1.3e-5 |x| of the exact-erf GELU (diffusers GEGLU -> F.gelu, approximate='none')."""
+    import re
+    from scipy.special import erf
+    src = open(os.path.join(os.path.dirname(__file__), "..", "sonicdiffusionbayeslab_amd", "csrc", "common.h")).read()
+    body = src[src.index("f32x2_t geglu_pair("):]
+    body = body[:body.index("return value * gate * phi")]
+    c = float(re.search(r"constexpr float C = ([0-9.]+)f", body).group(1))
+    ks = [float(v) for v in re.findall(r"k\((-?[0-9.]+e[+-][0-9]+)f\)", body)]
+    assert len(ks) == 10                                 # Horner order: highest power first
+    x = np.linspace(-12, 12, 480001).astype(np.float32)
+    xc = np.clip(x, -c, c).astype(np.float32)
+    u = (xc * np.float32(1.0 / c)) ** 2
+    p = np.full_like(u, np.float32(ks[0]))
+    for k in ks[1:]:
+        p = p * u + np.float32(k)
+    got = x * (np.float32(0.5) + xc * p)
+    x64 = x.astype(np.float64)
+    ref = x64 * 0.5 * (1 + erf(x64 / np.sqrt(2)))
+    assert (np.abs(got - ref) / np.maximum(np.abs(x64), 1e-3)).max() < 1.3e-5
