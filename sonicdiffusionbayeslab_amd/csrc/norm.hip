@@ -121,23 +121,29 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GroupNormArgs a)
 // wave per (batch, group) sums its channels over the blocks of its sample in a fixed order -> mean, rstd, written where
 // gn_apply_kernel reads them.  Replaces gn_stats_kernel + gn_finalize_kernel (no pass over the tensor).
 __global__ __launch_bounds__(256) void gn_finalize_stats_kernel(const GroupNormArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (idx >= a.B * a.groups) return;
+    // one 256-thread block per (batch, group): the (64-row block, channel) pairs of the group are strided over the
+    // threads, then a fixed-shape reduction (wave, then the four waves in order): deterministic
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x;
     const int b = idx / a.groups, gi = idx - b * a.groups;
     const int C = a.C1 + a.C2, cpg = C / a.groups, nblk = a.HW >> 6;
     const int total = nblk * cpg;                       // (block, channel) pairs of this group
     float s = 0.f, q = 0.f;
-    for (int i = lane; i < total; i += 64) {
+    for (int i = tid; i < total; i += 256) {
         const int blk = i / cpg, c = gi * cpg + (i - blk * cpg);
         const long gb = (long)b * nblk + blk;
-        const float* pp = c < a.C1 ? a.stats1 + (gb * a.C1 + c) * 2 : a.stats2 + (gb * a.C2 + (c - a.C1)) * 2;
-        s += pp[0];
-        q += pp[1];
+        const f32x2_t v = *(const f32x2_t*)(c < a.C1 ? a.stats1 + (gb * a.C1 + c) * 2 : a.stats2 + (gb * a.C2 + (c - a.C1)) * 2);
+        s += v[0];
+        q += v[1];
     }
     s = wave_sum(s);
     q = wave_sum(q);
-    if (lane == 0) {
+    if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        s = (red[0] + red[2]) + (red[4] + red[6]);
+        q = (red[1] + red[3]) + (red[5] + red[7]);
         const float cnt = (float)a.HW * (float)cpg;
         const float mean = s / cnt;
         const float var = fmaxf(q / cnt - mean * mean, 0.f);
@@ -505,7 +511,7 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     dim3 grid(a.nsplit, a.B);
     if (a.stats1 != nullptr) {
         SD_REQUIRE(a.HW % 64 == 0 && (a.C2 == 0 || a.stats2 != nullptr), "groupnorm: producer statistics need HW %% 64 == 0 and both sources");
-        hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3(a.B * a.groups), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), (g.threads + g.nchunks) * sizeof(float4), stream, a);
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
