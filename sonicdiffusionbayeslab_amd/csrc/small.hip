@@ -122,6 +122,83 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict_
     if (lane < Cout) y[(((long)b * Cout + lane) * H + oy) * W + ox] = mine + bias[lane];
 }
 
+// ---- conv_out on the matrix cores: D[cout (16 rows, <= 4 live)][16 pixels] += W[cout][k] . X[pixel][k], k = (tap, channel) ----
+// The wave-per-pixel kernel above re-reads the 4 x 9 x Cin weights for every pixel (23 KB of L1 traffic per pixel at
+// Cin = 320: 133 us for the 64x64 UNet output).  Here the weights sit in LDS once per workgroup, a wave owns T x 16 consecutive
+// pixels (T MFMA tiles) and streams their 9 shifted input rows straight from global memory into the B operand
+// (lane = (pixel, 8-channel group): 16 contiguous bytes each); out-of-image taps are zeroed after an unconditional load.
+template <int T>
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wp,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                            int H, int W, int Cin, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // W rows 0..3: [4][9 * Cin] bf16 (rows >= Cout zero)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = 9 * Cin;
+    for (int i = tid; i < 4 * (K / 8); i += 256) {
+        const int row = i / (K / 8);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < Cout) v = *(const u32x4*)(Wp + (long)i * 8);
+        *(u32x4*)(smem + (long)i * 16) = v;
+    }
+    __syncthreads();
+    const int l15 = lane & 15, kg = lane >> 4;
+    const long npix = (long)B * H * W;
+    const long pix0 = ((long)blockIdx.x * 4 + wave) * (16 * T);
+    if (pix0 >= npix) return;
+    int oy[T], ox[T];
+    long base[T];
+    bool valid[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const long pp = pix0 + t * 16 + l15;
+        valid[t] = pp < npix;
+        const long pc = valid[t] ? pp : npix - 1;
+        const int b = (int)(pc / (H * W));
+        const int rem = (int)(pc - (long)b * H * W);
+        oy[t] = rem / W;
+        ox[t] = rem - oy[t] * W;
+        base[t] = (long)b * H * W;
+    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* wrow = smem + ((long)(l15 & 3) * K + kg * 8) * 2;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const bf16_t* src[T];
+        bool ok[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int iy = oy[t] + tap / 3 - 1, ix = ox[t] + tap % 3 - 1;
+            ok[t] = valid[t] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            src[t] = x + (base[t] + (long)cy * W + cx) * Cin + kg * 8;
+        }
+#pragma unroll 10
+        for (int c0 = 0; c0 < Cin; c0 += 32) {
+            bf16x8 wf = *(const bf16x8*)(wrow + (tap * Cin + c0) * 2);
+            wf = l15 < 4 ? wf : zero8;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bf16x8 xf = *(const bf16x8*)(src[t] + c0);
+                xf = ok[t] ? xf : zero8;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (kg == 0) {          // lanes 0..15: rows (output channels) 0..3 of pixel l15
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (!valid[t]) continue;
+            const long b = base[t] / ((long)H * W);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < Cout) y[((b * Cout + j) * H + oy[t]) * W + ox[t]] = acc[t][j] + bias[j];
+        }
+    }
+}
+
 // ---- fused CFG + scheduler update ---------------------------------------------------------
 __global__ void sched_step_kernel(const float* __restrict__ eps, int cfg, float guidance,
                                   const float* __restrict__ x, const float* __restrict__ m1,
@@ -298,6 +375,19 @@ int sd_launch_conv_out(const bf16_t* x, const bf16_t* Wp, const float* bias, flo
     SD_REQUIRE(x && Wp && bias && y, "conv_out: null operand");
     SD_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "conv_out: Cin=%d Cout=%d", Cin, Cout);
     const long npix = (long)B * H * W;
+    static const bool no_mfma = getenv("SD_CONV_OUT_VALU") != nullptr;
+    const size_t smem = (size_t)4 * 9 * Cin * 2;
+    if (!no_mfma && Cin % 32 == 0 && smem <= 64 * 1024) {
+        static const int tiles = getenv("SD_CONV_OUT_TILES") ? atoi(getenv("SD_CONV_OUT_TILES")) : 1;
+        if (tiles == 2)
+            hipLaunchKernelGGL(conv_out_mfma_kernel<2>, dim3((unsigned)((npix + 127) / 128)), dim3(256), smem, stream, x, Wp, bias, y,
+                               B, H, W, Cin, Cout);
+        else
+            hipLaunchKernelGGL(conv_out_mfma_kernel<1>, dim3((unsigned)((npix + 63) / 64)), dim3(256), smem, stream, x, Wp, bias, y,
+                               B, H, W, Cin, Cout);
+        SD_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, stream, x, Wp, bias, y, B, H, W,
                        Cin, Cout);
     SD_CHECK_HIP(hipGetLastError());

@@ -335,6 +335,25 @@ def test_conv_in_out(sdlib):
     assert rel_l2(out2, ref2) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,Cout", [
+    (2, 64, 64, 320, 4),      # the UNet's conv_out
+    (1, 24, 40, 128, 3),      # the VAE decoder's: 3 channels, non-square image
+    (3, 5, 7, 64, 4),         # 105 pixels: ragged last tile, every pixel near a border
+])
+def test_conv_out_matrix_core_kernel(sdlib, B, H, W, C, Cout):
+    g = torch.Generator().manual_seed(H * W + C)
+    y = r16(torch.randn(B, C, H, W, generator=g))
+    w2 = r16(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b2 = torch.randn(Cout, generator=g)
+    ref = F.conv2d(y, w2, b2, padding=1)
+    yd = dev(y.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    wp = dev(w2.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    out = torch.full((B, Cout, H, W), float("nan"), device="cuda")
+    _lib.check(sdlib.sd_op_conv_out(stream(), P(yd), P(wp), P(b2), P(out), B, H, W, C, Cout))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 1e-5
+
+
 def test_time_embedding(sdlib):
     g = torch.Generator().manual_seed(5)
     w1 = r16(torch.randn(1280, 320, generator=g) / 18); b1 = torch.randn(1280, generator=g)

@@ -91,6 +91,11 @@ def main():
             ms = timeit(f)
             fl = 2.0 * UB * ho * ho * cout * 9 * cin
             print(f"conv res={res:3d} {cin:5d}->{cout:5d} s{stride} up{up}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
+    if not args.only or "convio" in args.only:
+        x = rnd(UB, 64, 64, 320); w = rnd(4, 9, 320); b = torch.zeros(4, device="cuda")
+        out = torch.empty(UB, 4, 64, 64, device="cuda")
+        ms = timeit(lambda: _lib.check(lib.sd_op_conv_out(st, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), UB, 64, 64, 320, 4)))
+        print(f"conv_out 64x64 320->4  {ms*1e3:8.1f} us  {x.numel()*2/ms/1e6:7.1f} GB/s read")
     if not args.only or "attn" in args.only:
         print("== attention ==")
         shapes = ((4096, 320, 0), (1024, 640, 0), (256, 1280, 0), (64, 1280, 0), (4096, 320, 77), (1024, 640, 77), (256, 1280, 77))
