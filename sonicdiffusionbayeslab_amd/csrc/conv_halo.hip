@@ -445,7 +445,7 @@ int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int u
     GemmArgs a;
     a.M = M; a.N = N; a.Cin = Cin; a.K = 9 * Cin; a.ldw = a.K; a.Hin = Hin; a.Win = Win; a.stride = stride; a.up = up; a.dt = dt;
     if (!env && sd_conv_halo_applicable(a)) return sd_conv_halo_splitk(M, N, Cin, dt);
-    return sd_gemm_splitk(M, N, dt ? 9 * Cin / 2 : 9 * Cin);      // the heuristic counts 128-byte K tiles
+    return sd_gemm_splitk(M, N, dt ? 9 * Cin / 2 : 9 * Cin, 128);      // the heuristic counts 128-byte K tiles
 }
 
 int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {

@@ -682,10 +682,18 @@ static bool big_tile_ok(int M, int N, int BN) {
 
 // Split-K factor for a (M, N, K) problem on the 128x160 tile: only when the tile grid cannot fill
 // the 256 CUs and K is long enough to amortise the fp32 slab round trip.
-int sd_gemm_splitk(int M, int N, int K) {
+// Rows of the plain GEMM's output tile: 64 x 160 when 128-row tiles would leave the 512 workgroup slots (2 per CU) less
+// than 3/4 full (the 16x16 and 8x8 levels: M = 4096 / 1024), else 128 x 160.  SD_GEMM_SMALL=0: always 128.
+int sd_gemm_tile_rows(int M, int N) {
+    static const bool off = getenv("SD_GEMM_SMALL") && atoi(getenv("SD_GEMM_SMALL")) == 0;
+    return (!off && M > 64 && ((M + 127) / 128) * ((N + 159) / 160) < 384) ? 64 : 128;
+}
+
+int sd_gemm_splitk(int M, int N, int K, int rows) {
     static const char* env = getenv("SD_SPLITK");
     if (env) return atoi(env) > 1 ? atoi(env) : 1;
-    const int tiles = ((M + 127) / 128) * ((N + 159) / 160);
+    if (rows == 0) rows = sd_gemm_tile_rows(M, N);
+    const int tiles = ((M + rows - 1) / rows) * ((N + 159) / 160);
     const int KT = K / 64;
     if (tiles >= 448) return 1;           // already ~2 workgroups per CU
     int want = (512 + tiles - 1) / tiles; // aim at two workgroups per CU (measured: 740 -> 980 TF/s at 16x16)
@@ -759,6 +767,8 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     if (a.rows_per_batch) return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);   // tiles must not straddle samples
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
     if (big_tile_mode() == 2) return launch<256, 160, 4, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
+    // (the 64-row tile's waves own 32 rows: no GroupNorm block statistics, no LayerNorm-fold consumer on it)
+    if (!a.stats && !a.ln_rs && sd_gemm_tile_rows(a.M, a.N) == 64) return launch<64, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
     return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
 }
 

@@ -54,7 +54,9 @@ struct GemmArgs {
     float oscale = 1.0f;              // ... of out * oscale
 };
 
-int sd_gemm_splitk(int M, int N, int K);   // heuristic split factor (1 = none) for the std epilogue
+int sd_gemm_tile_rows(int M, int N);        // 64 or 128: M tile of the plain (std epilogue) GEMM
+// heuristic split factor (1 = none) for the std epilogue; rows = M tile of the kernel that will run (0 = the plain bf16 GEMM's choice)
+int sd_gemm_splitk(int M, int N, int K, int rows = 0);   // heuristic split factor (1 = none) for the std epilogue
 int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu, 2 softmax over 80-column groups*/, hipStream_t stream);
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
 void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // slab -> C (+bias +bias2 +R)

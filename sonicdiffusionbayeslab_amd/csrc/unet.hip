@@ -815,7 +815,7 @@ struct Builder {
         o.b = b.empty() ? NOFF : W(b); o.r = r;
         if (fq > 0.f) { o.dt = 1; o.K = o.K1 = pad128(k1); o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = fq; }
         else o.w = W(w);
-        o.splitk = epi ? 1 : sd_gemm_splitk(M, N, o.dt ? o.K / 2 : o.K);     // the heuristic counts 128-byte K tiles
+        o.splitk = epi ? 1 : sd_gemm_splitk(M, N, o.dt ? o.K / 2 : o.K, o.dt ? 128 : 0);     // the heuristic counts 128-byte K tiles
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * M * N * 4);
         if (oq > 0.f) { o.out_fp8 = 1; o.os = oq; o.Cpad = pad128(N / 2); o.out = tensor((size_t)M * o.Cpad); }
         else o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
@@ -1792,7 +1792,7 @@ extern "C" int sd_op_gemm_fp8(void* stream, const void* X, long long ldx, const 
     a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.ldr = ldr;
     a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
     a.dt = 1; a.wscale = wscale; a.xscale_inv = 1.0f / xscale; a.out_fp8 = out_fp8; a.oscale = oscale;
-    a.splitk = epi ? 1 : sd_gemm_splitk(M, N, K / 2);
+    a.splitk = epi ? 1 : sd_gemm_splitk(M, N, K / 2, 128);
     if (a.splitk > 1) {
         a.slab = (float*)op_scratch((size_t)a.splitk * M * N * 4);
         SD_REQUIRE(a.slab, "sd_op_gemm_fp8: cannot allocate split-K scratch");
