@@ -188,6 +188,12 @@ int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float
                     float eps);
 int sd_op_attention(void* stream, const void* Q, long long ldq, const void* K, long long ldk, const void* V,
                     long long ldv, void* O, long long ldo, int B, int heads, int Nq, int Nk, int D, float scale);
+/* the same with HEAD-MAJOR K / V, [B][heads][Nk][D] contiguous (how the plan's fused q|k|v projection stores K and V at
+ * the 64x64 level: a 64-key tile of one head is one contiguous 5 KiB block for the LDS-DMA); d = 40, Nk % 64 == 0 */
+int sd_op_gemm_qkv_headmajor(void* stream, const void* X, long long ldx, const void* W, void* Q, void* KV, int M, int C,
+                             int tokens, int K);   /* the producer: Q [M][C], KV [2][M/tokens][C/40][tokens][40] */
+int sd_op_attention_headmajor(void* stream, const void* Q, long long ldq, const void* K, const void* V, void* O,
+                              long long ldo, int B, int heads, int Nq, int Nk, int D, float scale);
 int sd_op_conv_in(void* stream, const float* x, int Bsrc, const float* Wt, const float* bias, void* y, int B, int H,
                   int W, int Cin, int Cout);
 int sd_op_conv_out(void* stream, const void* x, const void* Wp, const float* bias, float* y, int B, int H, int W,

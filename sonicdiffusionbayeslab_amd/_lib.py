@@ -78,6 +78,8 @@ _SIGS = {
     "sd_op_conv3x3_groupnorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i]),
     "sd_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "sd_op_attention": (_i, [_vp, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f]),
+    "sd_op_gemm_qkv_headmajor": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "sd_op_attention_headmajor": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f]),
     "sd_op_conv_in": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "sd_op_conv_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "sd_op_time_embedding": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),

@@ -563,14 +563,18 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         if (inst < CHK) {
             const int ch = inst * 64 + lane, key = ch / CHK, part = ch - key * CHK;
             if (part < CD) {
-                d_ptr[j] = (const char*)(a.K + (long)b * a.Nk * a.ldk + head * D + (long)key * a.ldk + part * 8);
-                d_step[j] = 64 * a.ldk * 2;
+                const long ld = a.kv_head_major ? D : a.ldk;
+                const long base = a.kv_head_major ? ((long)b * a.heads + head) * a.Nk * D : (long)b * a.Nk * a.ldk + head * D;
+                d_ptr[j] = (const char*)(a.K + base + (long)key * ld + part * 8);
+                d_step[j] = 64 * ld * 2;
             }
         } else if (inst < NI) {
             const int ch = (inst - CHK) * 64 + lane, key = ch / CHV, part = ch - key * CHV;
             if (part < CD) {
-                d_ptr[j] = (const char*)(a.V + (long)b * a.Nk * a.ldv + head * D + (long)key * a.ldv + part * 8);
-                d_step[j] = 64 * a.ldv * 2;
+                const long ld = a.kv_head_major ? D : a.ldv;
+                const long base = a.kv_head_major ? ((long)b * a.heads + head) * a.Nk * D : (long)b * a.Nk * a.ldv + head * D;
+                d_ptr[j] = (const char*)(a.V + base + (long)key * ld + part * 8);
+                d_step[j] = 64 * ld * 2;
             } else if (part == CD) {
                 d_ptr[j] = ones;
             }
@@ -842,6 +846,12 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
     SD_REQUIRE(a.Q && a.K && a.V && a.O, "attention: null operand");
     SD_REQUIRE(a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0, "attention: empty problem");
+    if (a.kv_head_major) {
+        SD_REQUIRE(a.D == 40 && a.Nk % 64 == 0 && a.Nk >= 256 && a.consts != nullptr && a.ldq % 8 == 0 && a.ldo % 4 == 0 &&
+                       a.ldq >= (long)a.heads * a.D && a.ldo >= (long)a.heads * a.D,
+                   "attention: head-major K / V is built for d = 40 and key counts that are multiples of 64 (>= 256)");
+        return launch_attn_pipe40(a, stream);
+    }
     SD_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,
                "attention: row strides must keep 16-byte alignment");
     SD_REQUIRE(a.ldq >= (long)a.heads * a.D && a.ldk >= (long)a.heads * a.D && a.ldv >= (long)a.heads * a.D &&

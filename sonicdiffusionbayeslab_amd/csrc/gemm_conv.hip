@@ -516,6 +516,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         // 64 contiguous bytes per row per instruction.  After the swap lane group lq holds
         // lq=0: tile a cols 0-7, lq=1: tile a+1 cols 0-7, lq=2: tile a cols 8-15, lq=3: tile a+1 cols 8-15.
         const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64);
+        // destination of columns col.. of row m: C, or the head-major K / V block of this tile (GemmArgs::KV)
+        const bool hm = EPI == EPI_STD && p.hm_C > 0 && en0 >= p.hm_C;            // tile-uniform
+        bf16_t* hm_base = nullptr;
+        if (hm) {
+            const int which = en0 / p.hm_C - 1, head0 = (en0 - (which + 1) * p.hm_C) / 40, heads = p.hm_C / 40;
+            const int smp = em0 / p.hm_tok;
+            hm_base = p.KV + ((((long)which * (p.M / p.hm_tok) + smp) * heads + head0) * p.hm_tok - (long)smp * p.hm_tok) * 40;
+        }
+        auto out_ptr = [&](int m, int col) -> bf16_t* {
+            if (!hm) return p.C + (long)m * p.ldc + col;
+            const int cl = col - en0;                       // 0 .. 159: (head, channel) = (cl / 40, cl % 40)
+            const int hl = (cl * 205) >> 13;
+            return hm_base + ((long)hl * p.hm_tok + m) * 40 + (cl - hl * 40);
+        };
         auto store_narrow = [&](int a) {
             const int n = en0 + wn * WTN + a * 16 + lq * 4;
             if (n >= p.N) return;
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 const int m = em0 + wm * WTM + b * 16 + lrow;
                 const f32x4 v = acc[a][b];
                 u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                if (m < p.M && !(p.tune & 8)) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+                if (m < p.M && !(p.tune & 8)) *(u32x2*)out_ptr(m, n) = o;
             }
         };
 #pragma unroll
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                     const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
-                    if (m < p.M && !(p.tune & 8)) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+                    if (m < p.M && !(p.tune & 8)) *(u32x4*)out_ptr(m, col) = o;
                 }
             } else {
                 store_narrow(a);
@@ -718,6 +732,13 @@ static int check_stats(const GemmArgs& a, int epi) {
                "producer statistics: plain epilogue, M %% 64 == 0 and no split-K (M=%d splitk=%d)", a.M, a.splitk);
     return 0;
 }
+static int check_headmajor(const GemmArgs& a, int epi) {
+    if (!a.hm_C) return 0;
+    SD_REQUIRE(epi == EPI_STD && a.KV && a.hm_C % 160 == 0 && a.N == 3 * a.hm_C && a.hm_tok % 128 == 0 && a.M % a.hm_tok == 0 &&
+                   !(a.splitk > 1 && a.slab) && big_tile_mode() == 0 && sd_gemm_tile_rows(a.M, a.N) == 128,
+               "head-major K / V: N = 3 C with C %% 160 == 0, tokens per sample %% 128 == 0, 128 x 160 tiles, no split-K");
+    return 0;
+}
 static int check_ln(const GemmArgs& a, int epi) {
     if (a.rowstats) SD_REQUIRE(epi == EPI_STD && !(a.splitk > 1 && a.slab), "LayerNorm partials: plain epilogue without split-K");
     if (!a.ln_rs) return 0;
@@ -728,7 +749,7 @@ static int check_ln(const GemmArgs& a, int epi) {
 }
 
 int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
-    if (check_stats(a, epi) || check_ln(a, epi)) return -1;
+    if (check_stats(a, epi) || check_ln(a, epi) || check_headmajor(a, epi)) return -1;
     if (a.dt == 1) {
         if (check_fp8(a, "gemm")) return -1;
         SD_REQUIRE(a.N % 4 == 0 && a.M > 0 && a.N > 0 && a.zero_page, "gemm fp8: bad problem");

@@ -41,6 +41,11 @@ struct GemmArgs {
     // the epilogue turns the raw sums into  rstd_m * (acc - mean_m * c1[n]) + bias[n]  with mean / rstd of row m
     // from its ln_np partials ln_rs[part][M][2] (K = the normalised width).
     float* rowstats = nullptr;
+    // q|k|v projection with HEAD-MAJOR K / V (std epilogue): columns [0, hm_C) (Q) go to C as usual, the 160-column tiles of
+    // K (columns [hm_C, 2 hm_C)) and V are stored as KV[which][sample][head][token][40]: a 64-key tile of one head is one
+    // contiguous 5 KiB block for the self-attention's LDS-DMA.  Needs head dim 40, hm_C % 160 == 0, hm_tok % 128 == 0.
+    bf16_t* KV = nullptr;
+    int hm_C = 0, hm_tok = 0;
     const float* ln_rs = nullptr;
     const float* ln_c1 = nullptr;
     int ln_np = 0;
@@ -110,6 +115,9 @@ struct AttnArgs {
     int B = 0, heads = 0, Nq = 0, Nk = 0, D = 0;
     float scale = 0.f;
     const void* consts = nullptr;   // device page: 16 zero bytes at +0, the bf16 chunk {1,0,0,0,0,0,0,0} at +256
+    // HEAD-MAJOR K / V ([B][heads][Nk][D] contiguous: a 64-key tile of one head is 64 * D * 2 contiguous bytes, so the
+    // LDS-DMA pieces of the 64x64 self-attention touch 8 cache lines instead of ~26); 0 = token-major as Q (ldk / ldv)
+    int kv_head_major = 0;
 };
 int sd_launch_attention(const AttnArgs& a, hipStream_t stream);
 

@@ -114,6 +114,7 @@ struct Op {
     int stats = -1, s1 = -1, s2 = -1;
     // LayerNorm fold: rs = row partials this op writes ([np][M][2] fp32); lnrs / lnnp / c1 = partials and column sums
     // this GEMM normalises with (its x1 is the un-normalised tensor, its weights carry gamma, its bias W beta + b)
+    int hm = 0;                       // GEMM: q|k|v with head-major K / V (HW = tokens per sample); ATTN: K / V are head-major
     int rs = -1, lnrs = -1, lnnp = 0;
     size_t c1 = NOFF;
     size_t wsc = NOFF;
@@ -863,7 +864,21 @@ struct Builder {
             int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias", fq);
             qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0, sn);
         }
-        int a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
+        // 64x64 level (head dim 40): the projection stores K and V head-major, [which][sample][head][token][40] behind the
+        // token-major Q block, so that the self-attention's LDS-DMA pieces are contiguous (SD_ATTN_HEADMAJOR=0: off)
+        static const bool hm_off = (getenv("SD_ATTN_HEADMAJOR") && atoi(getenv("SD_ATTN_HEADMAJOR")) == 0) ||
+                                   getenv("SD_ATTN_NO_PIPE") || getenv("SD_ATTN_NO_DMA") || getenv("SD_GEMM_BIG");
+        const bool hm = !hm_off && C / u->cfg.num_heads == 40 && C % 160 == 0 && hw % 128 == 0 && hw >= 256 &&
+                        sd_gemm_tile_rows(M, 3 * C) == 128 && pl.ops.back().splitk == 1;
+        int a1;
+        if (hm) {
+            pl.ops.back().hm = 1;
+            pl.ops.back().HW = hw;
+            a1 = attn(qkv, 0, C, qkv, (long)M * C, 2l * M * C, C, hw, hw, C);
+            pl.ops.back().hm = 1;
+        } else {
+            a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
+        }
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
         int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
         // K|V of the prompt: projected once per sampling run by sd_unet_set_context
@@ -1263,6 +1278,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             if (o.out_fp8) { a.out_fp8 = 1; a.oscale = o.os; a.ldc = o.Cpad; }
             a.stats = (float*)T(o.stats);
             a.rowstats = (float*)T(o.rs);
+            if (o.hm) { a.hm_C = o.N / 3; a.hm_tok = o.HW; a.ldc = a.hm_C; a.KV = (bf16_t*)T(o.out) + (long)o.M * a.hm_C; }
             if (o.lnrs >= 0) { a.ln_rs = (const float*)T(o.lnrs); a.ln_np = o.lnnp; a.ln_c1 = (const float*)(wb + o.c1); a.ln_eps = 1e-5f; }
             return sd_launch_gemm(a, o.epi, stream);
         }
@@ -1281,6 +1297,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.B = o.B; a.heads = o.heads; a.Nq = o.Nq; a.Nk = o.Nk; a.D = o.D;
             a.scale = 1.0f / sqrtf((float)o.D);
             a.consts = g_zero_page;
+            a.kv_head_major = o.hm;
             return sd_launch_attention(a, stream);
         }
         case OP_XATTN: {
@@ -1757,6 +1774,29 @@ extern "C" int sd_op_attention(void* stream, const void* Q, long long ldq, const
                                long long ldv, void* O, long long ldo, int B, int heads, int Nq, int Nk, int D, float scale) {
     AttnArgs a;
     a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+    a.O = (bf16_t*)O; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
+    if (ensure_zero_page()) return -2;
+    a.consts = g_zero_page;
+    return sd_launch_attention(a, (hipStream_t)stream);
+}
+
+// q|k|v projection the way the plan runs it at the 64x64 level: Q token-major [M][C], K and V head-major
+// KV[2][M / tokens][C / 40][tokens][40] (GemmArgs::KV); W = [3 C][K] rows (q | k | v)
+extern "C" int sd_op_gemm_qkv_headmajor(void* stream, const void* X, long long ldx, const void* W, void* Q, void* KV, int M,
+                                        int C, int tokens, int K) {
+    if (ensure_zero_page()) return -2;
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.C = (bf16_t*)Q; a.ldc = C; a.M = M; a.N = 3 * C;
+    a.K = K; a.zero_page = g_zero_page; a.splitk = 1; a.KV = (bf16_t*)KV; a.hm_C = C; a.hm_tok = tokens;
+    return sd_launch_gemm(a, 0, (hipStream_t)stream);
+}
+
+// self-attention with HEAD-MAJOR K / V ([B][heads][Nk][D] contiguous, as the plan's q|k|v projection stores them at the
+// 64x64 level): d = 40, Nk a multiple of 64
+extern "C" int sd_op_attention_headmajor(void* stream, const void* Q, long long ldq, const void* K, const void* V, void* O,
+                                         long long ldo, int B, int heads, int Nq, int Nk, int D, float scale) {
+    AttnArgs a;
+    a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.kv_head_major = 1;
     a.O = (bf16_t*)O; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
     if (ensure_zero_page()) return -2;
     a.consts = g_zero_page;

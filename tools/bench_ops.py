@@ -111,6 +111,12 @@ def main():
             ms = timeit(f)
             fl = 4.0 * UB * 8 * hw * Nk * D
             print(f"attn N={hw:5d} Nk={Nk:5d} D={D:4d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
+            if D == 40 and nk == 0:
+                kh, vh = rnd(UB, 8, Nk, D), rnd(UB, 8, Nk, D)
+                f = lambda: _lib.check(lib.sd_op_attention_headmajor(st, q.data_ptr(), C, kh.data_ptr(), vh.data_ptr(), out.data_ptr(), C,
+                                                                     UB, 8, hw, Nk, D, 1 / math.sqrt(D)))
+                ms = timeit(f)
+                print(f"attn N={hw:5d} Nk={Nk:5d} D={D:4d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s  (head-major K / V)")
     if not args.only or "norm" in args.only:
         print("== norms ==")
         for (hw, c1, c2) in ((4096, 320, 0), (4096, 640, 320), (4096, 320, 320), (1024, 640, 0), (1024, 1280, 640), (256, 1280, 0), (256, 1280, 1280), (64, 1280, 1280)):
