@@ -131,6 +131,7 @@ int sd_launch_f32_to_bf16(const float* src, bf16_t* dst, long n, hipStream_t str
 int sd_launch_transpose_bf16(const bf16_t* src, bf16_t* dst, int B, int R, int Cc, hipStream_t stream, int perm16 = 0);
 
 int sd_launch_retile32(const bf16_t* src, bf16_t* dst, int B, int R, int K, int RT, hipStream_t stream);
+int sd_launch_replicate(const void* src, void* dst, long bytes, int rep, hipStream_t stream);   // dst[r][i] = src[i], r < rep
 
 // xattn.hip: fused prompt cross-attention  Y = R + sum_h softmax_L(X A_h) B_h + b_o  (one launch per block)
 struct XattnArgs {

@@ -340,6 +340,24 @@ __global__ void retile32_kernel(const bf16_t* __restrict__ src, bf16_t* __restri
     *(u32x4*)(dst + ((long)b * R * K) + d * 8) = v;
 }
 
+// dst[r][i] = src[i] for r < rep: the prompt-independent prefix of a CFG forward is computed once per latent and handed
+// to the conditional / unconditional halves (16-byte vectors; n16 = bytes / 16 of ONE copy)
+__global__ void replicate_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long n16, int rep) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    const u32x4 v = src[i];
+    for (int r = 0; r < rep; ++r) dst[(long)r * n16 + i] = v;
+}
+
+int sd_launch_replicate(const void* src, void* dst, long bytes, int rep, hipStream_t stream) {
+    SD_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0 && rep >= 1, "replicate: bytes=%ld rep=%d", bytes, rep);
+    const long n16 = bytes / 16;
+    hipLaunchKernelGGL(replicate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (const u32x4*)src, (u32x4*)dst,
+                       n16, rep);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int sd_launch_retile32(const bf16_t* src, bf16_t* dst, int B, int R, int K, int RT, hipStream_t stream) {
     SD_REQUIRE(src && dst && B > 0 && B <= 65535 && K % 32 == 0 && RT > 0 && R % RT == 0, "retile32: B=%d R=%d K=%d RT=%d", B, R, K, RT);
     const long per = (long)R * K / 8;

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -83,7 +84,7 @@ struct Wrap {  // one DeepCache-wrapped module enclosing an op
 };
 
 enum OpKind { OP_SINUSOID, OP_GEMV, OP_CONV_IN, OP_GN, OP_CONV3, OP_GEMM, OP_LN, OP_ATTN, OP_CONV_OUT, OP_SOFTMAX, OP_PQCONV,
-              OP_CLIP_EMBED, OP_CLIP_ATTN, OP_QGELU, OP_TO_F32, OP_XATTN };
+              OP_CLIP_EMBED, OP_CLIP_ATTN, OP_QGELU, OP_TO_F32, OP_XATTN, OP_REPLICATE };
 
 struct Op {
     int kind = 0;
@@ -127,11 +128,13 @@ struct Tn {
     size_t bytes = 0;
     int def = -1, last = -1;
     bool persistent = false;
+    bool ctx = false;            // written by sd_unet_set_context: same offset in every plan variant of a (batch, branch)
     size_t off = NOFF;
 };
 
 struct Plan {
     int UB = 0, branch = -1;
+    int rep = 1;                          // 2: the prompt-independent prefix runs once per latent (CFG pair), see Builder::build
     std::vector<Tn> tensors;
     std::vector<Op> ops;
     std::vector<char> skipped;            // per op: skipped on a DeepCache skip step
@@ -162,7 +165,8 @@ struct sd_unet {
     bool debug_taps = false;
     bool fp8 = false;                  // cfg.weight_dtype == SD_DTYPE_FP8_E4M3
     float s_norm = 8.f, s_ff = 2.f;    // fp8 activation scales (GroupNorm / LayerNorm outputs, GEGLU outputs)
-    std::map<std::pair<int, int>, Plan> plans;
+    std::map<std::tuple<int, int, int>, Plan> plans;     // (UNet batch, DeepCache branch, prefix replication)
+    int last_rep = 1;                                    // variant of the last forward (sd_unet_debug_tensor)
     std::unordered_map<std::string, long> tproj_off;  // resnet prefix -> float index into tproj vector
     long tproj_total = 0;
 };
@@ -734,6 +738,17 @@ struct Builder {
         stats_of[o.out] = o.stats;
     }
 
+    // CFG de-duplication (Plan::rep == 2: the UNet batch is [uncond | cond] over the SAME latents and timestep): every op
+    // before the first prompt cross-attention -- conv_in, down_blocks.0.resnets.0 and attentions.0 up to attn1.to_out --
+    // sees identical inputs in both halves, so it runs once per latent (UB / 2) and its three outputs that live on
+    // (conv_in's skip, the block input = proj_out's residual, h1) are copied to both halves.  prefix_rep > 1 while the
+    // builder is inside that prefix.
+    int prefix_rep = 1;
+    int replicate(int t, size_t bytes, int r) {
+        Op o; o.kind = OP_REPLICATE; o.x1 = t; o.M = (int)(bytes / 16); o.N = r; o.out = tensor(bytes * r);
+        push(o);
+        return o.out;
+    }
     // SD_LN_FOLD=0: every LayerNorm is its own launch (round-1 behaviour)
     bool ln_fold = !(getenv("SD_LN_FOLD") && atoi(getenv("SD_LN_FOLD")) == 0);
     // Ask the op that produced a residual-stream tensor for per-row LayerNorm partials; returns the partial count (0 =
@@ -755,6 +770,11 @@ struct Builder {
         return o.out;
     }
 
+    int ctx_tensor(size_t bytes) {       // persistent and written by sd_unet_set_context
+        const int id = tensor(bytes, true);
+        pl.tensors[id].ctx = true;
+        return id;
+    }
     int tensor(size_t bytes, bool persistent = false) {
         Tn t;
         t.bytes = (bytes + 255) / 256 * 256;
@@ -851,7 +871,8 @@ struct Builder {
     }
     // Transformer2DModel with one BasicTransformerBlock (A.4)
     int transformer(const std::string& p, int x, int C, int res) {
-        const int hw = res * res, M = UB * hw, L = u->cfg.context_len;
+        const int hw = res * res, L = u->cfg.context_len;
+        int M = UB * hw;
         const std::string t = p + "transformer_blocks.0.";
         const bool fq = u->fp8;
         const float sn = fq ? u->s_norm : 0.f, sf = fq ? u->s_ff : 0.f;
@@ -880,9 +901,16 @@ struct Builder {
             a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
         }
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
+        if (prefix_rep > 1) {        // end of the prompt-independent prefix: both CFG halves continue from copies
+            x = replicate(x, (size_t)M * C * 2, prefix_rep);
+            h1 = replicate(h1, (size_t)M * C * 2, prefix_rep);
+            UB *= prefix_rep;
+            M = UB * hw;
+            prefix_rep = 1;
+        }
         int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
         // K|V of the prompt: projected once per sampling run by sd_unet_set_context
-        int kv = tensor((size_t)UB * L * 2 * C * 2, /*persistent=*/true);
+        int kv = ctx_tensor((size_t)UB * L * 2 * C * 2);
         pl.ctx_kv.push_back(kv);
         pl.ctx_w.push_back(W(t + "attn2.kv.weight"));
         pl.ctx_c.push_back(C);
@@ -899,13 +927,13 @@ struct Builder {
         static const int fold_max_hw = getenv("SD_XATTN_FOLD") ? atoi(getenv("SD_XATTN_FOLD")) : 1024;
         const int NH = u->cfg.num_heads, NP = NH * 80;
         if (fused_min_hw > 0 && hw >= fused_min_hw && sd_xattn_fused_applicable(hw, C, NH, L)) {
-            int at = tensor((size_t)UB * NP * C * 2, true), bw = tensor((size_t)UB * C * NP * 2, true);
+            int at = ctx_tensor((size_t)UB * NP * C * 2), bw = ctx_tensor((size_t)UB * C * NP * 2);
             pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight"), true});
             Op o; o.kind = OP_XATTN; o.x1 = n2; o.r = h1; o.wt = at; o.x2 = bw; o.M = M; o.N = C; o.K = NP; o.rpb = hw;
             o.sm_valid = L; o.b = W(t + "attn2.to_out.0.bias"); o.heads = NH;
             o.out = tensor((size_t)M * C * 2); push(o); h2 = o.out;
         } else if (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) {
-            int at = tensor((size_t)UB * NP * C * 2, true), bw = tensor((size_t)UB * C * NP * 2, true);
+            int at = ctx_tensor((size_t)UB * NP * C * 2), bw = ctx_tensor((size_t)UB * C * NP * 2);
             pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight"), false});
             int pr;
             { Op o; o.kind = OP_GEMM; o.x1 = n2; o.K1 = C; o.K = C; o.M = M; o.N = NP; o.epi = 2; o.sm_valid = L;
@@ -1041,9 +1069,9 @@ struct Builder {
         const sd_unet_config& c = u->cfg;
         const int nl = c.num_levels, c0 = c.block_out_channels[0], temb = 4 * c0;
         const int L = c.context_len;
-        pl.ctx_bf16 = tensor((size_t)UB * L * c.cross_attention_dim * 2, true);
+        pl.ctx_bf16 = ctx_tensor((size_t)UB * L * c.cross_attention_dim * 2);
         // masked K / V expansions used by sd_unet_set_context for the folded cross-attention (sized for the widest level)
-        pl.ctx_fold_scratch = tensor((size_t)3 * UB * c.num_heads * 80 * c.block_out_channels[nl - 1] * 2, true);
+        pl.ctx_fold_scratch = ctx_tensor((size_t)3 * UB * c.num_heads * 80 * c.block_out_channels[nl - 1] * 2);
         // ---- time embedding (M = 1: the reference passes one scalar t per call) ----
         int t_sin = tensor((size_t)c0 * 4), t_h1 = tensor((size_t)temb * 4), t_emb = tensor((size_t)temb * 4);
         int t_proj = tensor((size_t)u->tproj_total * 4);
@@ -1054,11 +1082,13 @@ struct Builder {
         // ---- conv_in ----
         int res = c.sample_size;
         int h;
+        if (pl.rep > 1) { prefix_rep = pl.rep; UB /= pl.rep; }       // (restored by the first transformer block)
         { Op o; o.kind = OP_CONV_IN; o.x1 = T_LATENTS; o.B = UB; o.Hin = res; o.Win = res; o.Cin = c.in_channels; o.N = c0;
           o.w = W("conv_in.weight"); o.b = W("conv_in.bias"); o.out = tensor((size_t)UB * res * res * c0 * 2); push(o); h = o.out; }
-        pl.taps["conv_in"] = h;
+        const int h_skip = prefix_rep > 1 ? replicate(h, (size_t)UB * res * res * c0 * 2, prefix_rep) : h;
+        pl.taps["conv_in"] = h_skip;
         int ch = c0;
-        std::vector<int> skips{h}, skip_ch{c0};
+        std::vector<int> skips{h_skip}, skip_ch{c0};
         // ---- down ----
         for (int i = 0; i < nl; ++i) {
             const int co = c.block_out_channels[i];
@@ -1176,8 +1206,10 @@ void assign_memory(sd_unet* u, Plan& pl) {
     }
     // persistent region
     size_t off = 0;
+    for (auto& t : pl.tensors)               // what sd_unet_set_context writes: first, so every variant agrees on it
+        if (t.ctx) { t.off = off; off += t.bytes; }
     for (auto& t : pl.tensors)
-        if (t.persistent) { t.off = off; off += t.bytes; }
+        if (t.persistent && !t.ctx) { t.off = off; off += t.bytes; }
     const size_t arena0 = off;
     // arena: first-fit over live intervals
     struct Live { size_t off, bytes; int last; };
@@ -1203,17 +1235,24 @@ void assign_memory(sd_unet* u, Plan& pl) {
     pl.total_bytes = high + 4096;
 }
 
-int get_plan(sd_unet* u, int UB, int branch, Plan** out) {
+// CFG de-duplication applies to a forward whose UNet batch is exactly two copies of the latent batch (SD_CFG_DEDUP=0: off)
+static int plan_rep(const sd_unet* u, int latent_batch, int unet_batch) {
+    static const bool off = getenv("SD_CFG_DEDUP") && atoi(getenv("SD_CFG_DEDUP")) == 0;
+    return (!off && u->kind == 0 && u->cfg.attn_levels[0] && latent_batch > 0 && unet_batch == 2 * latent_batch) ? 2 : 1;
+}
+
+int get_plan(sd_unet* u, int UB, int branch, Plan** out, int rep = 1) {
     SD_REQUIRE(u && u->finalized, "unet: parameters not finalized");
     SD_REQUIRE(UB > 0 && UB <= 4096, "unet: bad batch %d", UB);
     SD_REQUIRE(branch < 3 * u->cfg.num_levels, "unet: cache_branch_id %d out of range", branch);
     if (branch < 0) branch = -1;
-    auto key = std::make_pair(UB, branch);
+    auto key = std::make_tuple(UB, branch, rep);
     auto it = u->plans.find(key);
     if (it == u->plans.end()) {
         Plan pl;
         pl.UB = UB;
         pl.branch = branch;
+        pl.rep = rep;
         Builder b{u, pl, UB, {}};
         b.build();
         assign_memory(u, pl);
@@ -1308,6 +1347,8 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.rowstats = (float*)T(o.rs);
             return sd_launch_xattn_fused(a, stream);
         }
+        case OP_REPLICATE:
+            return sd_launch_replicate(T(o.x1), T(o.out), (long)o.M * 16, o.N, stream);
         case OP_CLIP_EMBED:
             return sd_launch_clip_embed((const int*)latents, (const bf16_t*)(wb + o.w), (const bf16_t*)(wb + o.g),
                                         (bf16_t*)T(o.out), o.M, o.Nk, o.N, u->clip.vocab_size, stream);
@@ -1494,7 +1535,12 @@ extern "C" long long sd_unet_debug_packed(const sd_unet* u, const char* key, voi
 extern "C" long long sd_unet_workspace_bytes(sd_unet* u, int unet_batch, int cache_branch_id) {
     Plan* pl;
     if (get_plan(u, unet_batch, cache_branch_id, &pl)) return -1;
-    return (long long)pl->total_bytes;
+    size_t bytes = pl->total_bytes;
+    if (unet_batch % 2 == 0 && plan_rep(u, unet_batch / 2, unet_batch) == 2) {      // the CFG-pair variant of the plan
+        if (get_plan(u, unet_batch, cache_branch_id, &pl, 2)) return -1;
+        bytes = std::max(bytes, pl->total_bytes);
+    }
+    return (long long)bytes;
 }
 
 extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, int unet_batch, int cache_branch_id,
@@ -1569,7 +1615,9 @@ extern "C" int sd_unet_forward(sd_unet* u, void* stream, const float* latents, i
     SD_REQUIRE(cache_mode >= 0 && cache_mode <= 2, "forward: cache_mode %d", cache_mode);
     SD_REQUIRE(cache_mode == SD_CACHE_OFF || cache_branch_id >= 0, "forward: DeepCache modes need cache_branch_id >= 0");
     Plan* pl;
-    int rc = get_plan(u, unet_batch, cache_branch_id, &pl);
+    const int rep = plan_rep(u, latent_batch, unet_batch);
+    u->last_rep = rep;
+    int rc = get_plan(u, unet_batch, cache_branch_id, &pl, rep);
     if (rc) return rc;
     SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "forward: workspace too small (%lld < %zu)", workspace_bytes,
                pl->total_bytes);
@@ -1607,6 +1655,9 @@ static void op_work(const Op& o, double* flops, double* bytes) {
         case OP_LN:
             *bytes = 2.0 * 2.0 * (double)o.M * o.N;
             break;
+        case OP_REPLICATE:
+            *bytes = 16.0 * o.M * (1.0 + o.N);
+            break;
         default:
             break;
     }
@@ -1621,7 +1672,9 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
                "forward_profiled: null argument");
     SD_REQUIRE(latent_batch > 0 && unet_batch % latent_batch == 0, "forward_profiled: bad batch");
     Plan* pl;
-    int rc = get_plan(u, unet_batch, cache_branch_id, &pl);
+    const int rep = plan_rep(u, latent_batch, unet_batch);
+    u->last_rep = rep;
+    int rc = get_plan(u, unet_batch, cache_branch_id, &pl, rep);
     if (rc) return rc;
     SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "forward_profiled: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1646,7 +1699,7 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
         const Op& o = pl->ops[which[j]];
         double fl, by;
         op_work(o, &fl, &by);
-        const int kd = o.kind == OP_XATTN ? 18 : (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
+        const int kd = o.kind == OP_XATTN ? 18 : o.kind == OP_REPLICATE ? 19 : (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
         kind_ms[kd] += ms; kind_launches[kd] += 1; kind_flops[kd] += fl; kind_bytes[kd] += by;
     }
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -1657,7 +1710,7 @@ extern "C" int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, 
                                     void* workspace, int unet_batch, int cache_branch_id) {
     SD_REQUIRE(u && u->debug_taps, "debug_tensor: create the handle with SD_DEBUG_TAPS=1 in the environment");
     Plan* pl;
-    int rc = get_plan(u, unet_batch, cache_branch_id, &pl);
+    int rc = get_plan(u, unet_batch, cache_branch_id, &pl, u->last_rep);
     if (rc) return rc;
     auto it = pl->taps.find(name);
     SD_REQUIRE(it != pl->taps.end(), "debug_tensor: unknown tap '%s'", name);
