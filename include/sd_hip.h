@@ -91,7 +91,10 @@ enum { SD_CACHE_OFF = 0, SD_CACHE_FULL_AND_STORE = 1, SD_CACHE_SKIP = 2 };
 
 /* eps = UNet(latent_model_input, t, encoder_hidden_states)  (src/models.py:217-235).
  * `latents` is fp32 NCHW [latent_batch,4,H,W]; with unet_batch = 2*latent_batch the CFG
- * duplication `torch.cat([latents]*2)` (src/models.py:217) is fused into conv_in.
+ * duplication `torch.cat([latents]*2)` (src/models.py:217) is fused: the two halves of the batch then see the same latents
+ * and timestep, so everything before the first prompt cross-attention (conv_in, down_blocks.0.resnets.0,
+ * attentions.0 up to attn1.to_out) is computed once per latent and copied to both halves -- the results are those of
+ * the duplicated batch (SD_CFG_DEDUP=0 in the environment computes the prefix twice instead).
  * `eps_out` is fp32 NCHW [unet_batch,4,H,W].  cache_mode selects the DeepCache plan
  * (full step that refreshes the cache / skip step that reuses it). */
 int sd_unet_forward(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,

@@ -80,3 +80,18 @@ def test_unet_forward_is_bitwise_reproducible_and_batch_consistent(small_unet):
     co = torch.cat([halves[0][2:], halves[1][2:]])
     ref = torch.cat([un, co])
     assert rel_l2(a, ref) < 2e-3          # different split-K factors reassociate fp32 sums, nothing more
+
+
+def test_cfg_prefix_deduplication_matches_explicitly_duplicated_latents(small_unet):
+    """A CFG forward (UNet batch = 2 x latent batch: `torch.cat([latents] * 2)` of src/models.py:222) runs everything before
+    the first prompt cross-attention once per latent and copies it to both halves; handing the library the duplicated
+    latents as an ordinary batch (latent batch == UNet batch: no de-duplication) must give the same noise prediction up
+    to the reassociation of fp32 partial sums that a different batch size selects."""
+    cfg, sd, net = small_unet
+    lat, pe, ne = synth_inputs(cfg, 3, seed=11)
+    net.set_context(torch.cat([ne, pe]).cuda())
+    dedup = net.forward_latents(lat.cuda(), 6, 741.0).clone()
+    plain = net.forward_latents(torch.cat([lat, lat]).cuda(), 6, 741.0).clone()
+    assert torch.isfinite(dedup).all()
+    assert not torch.equal(dedup[:3], dedup[3:])          # the halves differ (different prompts) ...
+    assert rel_l2(dedup, plain) < 2e-3                    # ... and agree with the computation done twice
