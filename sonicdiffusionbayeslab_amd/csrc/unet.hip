@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -494,6 +495,48 @@ struct Packer {
             c2[n] = (float)s2;
         }
     }
+    // ff.net.2 and proj_out are two linear maps with only a residual add between them:
+    //   out = (ff W2^T + b2 + h2) Wpo^T + bpo + x  =  [ff | h2] . [Wpo W2 | Wpo]^T + (Wpo b2 + bpo) + x
+    // -> ONE GEMM with a two-segment K (4C + C) instead of two launches and the h3 round trip.  The product Wpo W2 is
+    // formed here once, in fp32 from the fp32 parameters, and rounded to bf16 like every other weight.
+    void ff_out_merge(const std::string& p, const std::string& t, int C) {
+        const auto& w2 = P(t + "ff.net.2.weight");      // [C][4C]
+        const auto& b2 = P(t + "ff.net.2.bias");
+        const auto& wpo = P(p + "proj_out.weight");     // [C][C]
+        const auto& bpo = P(p + "proj_out.bias");
+        const int K4 = 4 * C, KT = 5 * C;
+        std::vector<float> prod((size_t)C * K4, 0.f);
+        const int nthreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        auto work = [&](int tid) {
+            constexpr int NB = 8;                        // output rows per pass over W2
+            for (int n0 = tid * NB; n0 < C; n0 += nthreads * NB) {
+                const int nb = std::min(NB, C - n0);
+                for (int c = 0; c < C; ++c) {
+                    const float* row = &w2[(size_t)c * K4];
+                    for (int i = 0; i < nb; ++i) {
+                        const float a = wpo[(size_t)(n0 + i) * C + c];
+                        float* dst = &prod[(size_t)(n0 + i) * K4];
+                        for (int k = 0; k < K4; ++k) dst[k] += a * row[k];
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < nthreads; ++i) th.emplace_back(work, i);
+        work(0);
+        for (auto& x : th) x.join();
+        const size_t woff = alloc(p + "ff_out.weight", (size_t)C * KT * 2);
+        const size_t boff = alloc(p + "ff_out.bias", (size_t)C * 4);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + woff);
+        float* bo = (float*)(u->hblob.data() + boff);
+        for (int n = 0; n < C; ++n) {
+            for (int k = 0; k < K4; ++k) o[(size_t)n * KT + k] = f32_to_bf16_host(prod[(size_t)n * K4 + k]);
+            for (int c = 0; c < C; ++c) o[(size_t)n * KT + K4 + c] = f32_to_bf16_host(wpo[(size_t)n * C + c]);
+            double acc = bpo[n];
+            for (int c = 0; c < C; ++c) acc += (double)wpo[(size_t)n * C + c] * b2[c];
+            bo[n] = (float)acc;
+        }
+    }
     void geglu(const std::string& t, int C) {  // rows: every 32 = [16 value | 16 gate]
         const auto& w = P(t + "ff.net.0.proj.weight");
         const auto& b = P(t + "ff.net.0.proj.bias");
@@ -569,6 +612,7 @@ struct Packer {
         geglu(t, c);
         f32(t + "ff.net.2.bias");
         bf16_same(p + "proj_out.weight"); f32(p + "proj_out.bias");
+        if (!u->fp8) ff_out_merge(p, t, c);
     }
 };
 
@@ -953,11 +997,18 @@ struct Builder {
             int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias", fq);
             ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, sn, sf);
         }
-        int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, sf);
-        const int out = gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
-        if (pl.ops.back().splitk == 1) {          // the block's output feeds the next resnet's GroupNorm
-            want_stats(pl.ops.back(), M, C);
+        // ff.net.2 + residual + proj_out + residual as ONE GEMM over [ff | h2] (Packer::ff_out_merge; SD_FF_MERGE=0: two)
+        static const bool merge_off = getenv("SD_FF_MERGE") && atoi(getenv("SD_FF_MERGE")) == 0;
+        int out;
+        if (!fq && !merge_off) {
+            out = gemm(ff, 4 * C, h2, C, M, C, p + "ff_out.weight", p + "ff_out.bias", x, 0);
+        } else {
+            int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, sf);
+            out = gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
         }
+        // the block's output feeds the next resnet's GroupNorm (not at the small levels: their GroupNorms are single-launch or
+        // fall back to their own pass, and the statistics epilogue would keep this GEMM on 128-row tiles)
+        if (pl.ops.back().splitk == 1 && sd_gemm_tile_rows(M, C) == 128) want_stats(pl.ops.back(), M, C);
         return out;
     }
 
