@@ -374,6 +374,23 @@ def test_finalize_packs_weights_on_the_host(dtype):
         got = packed(p + "conv1.weight", w.numel() * 2, torch.bfloat16).view(640, 5, 9, 64)
         assert torch.equal(got.float(), w.permute(0, 2, 3, 1).reshape(640, 9, 5, 64).permute(0, 2, 1, 3).bfloat16().float())
         assert lib.sd_unet_debug_packed(h, (p + "conv1.weight.fp8").encode(), None, 0) < 0
+        # ff.net.2 + proj_out merged into one two-segment-K GEMM: rows [bf16(Wpo W2) | bf16(Wpo)], bias Wpo b2 + bpo
+        a = "down_blocks.0.attentions.0."
+        t = a + "transformer_blocks.0."
+        w2, b2 = sd[t + "ff.net.2.weight"].double(), sd[t + "ff.net.2.bias"].double()
+        wpo, bpo = sd[a + "proj_out.weight"].double().view(320, 320), sd[a + "proj_out.bias"].double()
+        got = packed(a + "ff_out.weight", 320 * 1600 * 2, torch.bfloat16).view(320, 1600).float()
+        want = torch.cat([wpo @ w2, wpo], dim=1).float()
+        assert (got - want).abs().max() <= 2.0 ** -8 * want.abs().max()                  # one bf16 rounding of an fp32 product
+        assert torch.equal(got[:, 1280:], wpo.float().bfloat16().float())
+        assert torch.allclose(packed(a + "ff_out.bias", 320 * 4, torch.float32), (wpo @ b2 + bpo).float(), rtol=1e-5, atol=1e-6)
+        # LayerNorm folded into q|k|v: rows bf16(W gamma), c1 = sum of the ROUNDED row, c2 = W beta
+        g1, be1 = sd[t + "norm1.weight"].float(), sd[t + "norm1.bias"].double()
+        rows = torch.cat([sd[t + f"attn1.to_{x}.weight"] for x in "qkv"]).float()
+        got = packed(t + "attn1.qkv.weight.ln", 960 * 320 * 2, torch.bfloat16).view(960, 320)
+        assert torch.equal(got, (rows * g1[None, :]).bfloat16())
+        assert torch.allclose(packed(t + "attn1.qkv.weight.c1", 960 * 4, torch.float32), got.double().sum(1).float(), rtol=1e-6, atol=1e-6)
+        assert torch.allclose(packed(t + "attn1.qkv.weight.c2", 960 * 4, torch.float32), (rows.double() @ be1).float(), rtol=1e-5, atol=1e-6)
     else:
         q, scale = quantize_rows(w)
         codes = q.to(torch.float8_e4m3fn).view(torch.uint8)          # [640, 320, 3, 3]
