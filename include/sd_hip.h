@@ -179,6 +179,12 @@ int sd_op_gemm_batched(void* stream, const void* X, long long ldx, const void* W
  * [Cout][Cin/64][3*3][64] (K runs over 64-channel slice, tap, channel) */
 int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2, const void* R,
                   void* Y, int B, int Hin, int Win, int Cin, int Cout, int stride, int upsample);
+/* Upsample2D (nearest 2x, then 3x3 conv; diffusers resnet.py, the UNet's three upsamplers) as four 2x2 convs on the
+ * LOW-RES input -- one per output sub-pixel phase -- with the 3x3 taps that read the same low-res pixel summed: 4/9 of
+ * the multiply-adds, the same linear map.  W4 = bf16 [4 phases (py, px)][Cout][Cin/64][4 taps (dy, dx)][64];
+ * needs Hin * Win % 128 == 0.  Y = [B, 2 Hin, 2 Win, Cout]. */
+int sd_op_conv3x3_upsample_subpixel(void* stream, const void* X, const void* W4, const float* bias, void* Y, int B, int Hin,
+                                    int Win, int Cin, int Cout);
 int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
                     const float* beta, void* y, int B, int HW, int groups, float eps, int silu);
 /* conv3x3 (stride 1) -> GroupNorm(+SiLU) the way the forward plan runs every resnet's conv -> norm pair

@@ -117,6 +117,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         if (AMODE == AMODE_GEMM) {
             xptr[i] = m < p.M ? (const char*)p.X + (long)m * p.ldx * ESZ + gch * 16 : nullptr;
             if (p.X2) xptr2[i] = m < p.M ? (const char*)p.X2 + (long)m * p.ldx2 * ESZ + gch * 16 : nullptr;
+        } else if (p.subpix) {
+            // sub-pixel upsample conv: row m = (sample, phase, low-res pixel); 2x2 taps from (y - 1 + py, x - 1 + px)
+            const int hwl = p.Hin * p.Win;
+            const int b = m / (4 * hwl), rem = m - b * 4 * hwl;
+            const int ph = rem / hwl, ml = rem - ph * hwl;
+            const int y = ml / p.Win, x = ml - y * p.Win;
+            const int y0 = y - 1 + (ph >> 1), x0 = x - 1 + (ph & 1);
+            xoy[i] = y0; xox[i] = x0; xb[i] = m < p.M ? b * hwl : -1;
+            xptr[i] = (const char*)p.X + ((long)b * hwl + (long)y0 * p.Win + x0) * p.Cin * ESZ + gch * 16;
+            int mask = 0;
+            if (m < p.M) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ty = y0 + (t >> 1), tx = x0 + (t & 1);
+                    if (ty >= 0 && ty < p.Hin && tx >= 0 && tx < p.Win) mask |= 1 << t;
+                }
+            }
+            xmask[i] = mask;
         } else {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
@@ -139,7 +157,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     for (int i = 0; i < WPW; ++i) {
         const int inst = wave + i * NW;
         const int n = n0 + inst * 8 + lrow8;
-        const long wb = p.rows_per_batch > 0 ? (long)(m0 / p.rows_per_batch) * p.w_batch_stride : 0;
+        const long wb = p.subpix ? (long)((m0 / (p.Hin * p.Win)) & 3) * p.w_batch_stride
+                                 : p.rows_per_batch > 0 ? (long)(m0 / p.rows_per_batch) * p.w_batch_stride : 0;
         wsrc[i] = (inst < WI && n < p.N) ? (const char*)p.W + (wb + (long)n * p.ldw) * ESZ + gch * 16 : nullptr;
     }
     };
@@ -161,8 +180,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 glds16(src, xs + inst * 1024);
             }
         } else {
-            const int cs = kt / 9, tap = kt - cs * 9;
-            const int dy = tap / 3, dx = tap - dy * 3;
+            const int nt = p.subpix ? 4 : 9, tw = p.subpix ? 2 : 3;        // taps per channel slice, taps per row
+            const int cs = kt / nt, tap = kt - cs * nt;
+            const int dy = tap / tw, dx = tap - dy * tw;
             if (!p.up) {
                 const long toff = (((long)dy * p.Win + dx) * p.Cin + cs * KTE) * ESZ;   // wave-uniform
 #pragma unroll
@@ -525,6 +545,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             hm_base = p.KV + ((((long)which * (p.M / p.hm_tok) + smp) * heads + head0) * p.hm_tok - (long)smp * p.hm_tok) * 40;
         }
         auto out_ptr = [&](int m, int col) -> bf16_t* {
+            if (AMODE == AMODE_CONV && p.subpix) {          // (sample, phase, low-res pixel) -> output pixel (2y+py, 2x+px)
+                const int hwl = p.Hin * p.Win;
+                const int b = m / (4 * hwl), rem = m - b * 4 * hwl;
+                const int ph = rem / hwl, ml = rem - ph * hwl;
+                const int y = ml / p.Win, x = ml - y * p.Win;
+                const long orow = ((long)b * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
+                return p.C + orow * p.ldc + col;
+            }
             if (!hm) return p.C + (long)m * p.ldc + col;
             const int cl = col - en0;                       // 0 .. 159: (head, channel) = (cl / 40, cl % 40)
             const int hl = (cl * 205) >> 13;
@@ -800,6 +828,13 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
         SD_REQUIRE(a.Cin % 128 == 0, "conv3x3 fp8: Cin=%d must be a multiple of 128 (pad the channels)", a.Cin);
     }
     SD_REQUIRE(a.Cin % 64 == 0, "conv3x3: Cin=%d must be a multiple of 64", a.Cin);
+    if (a.subpix) {     // nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-res input (GemmArgs::subpix)
+        SD_REQUIRE(a.dt == 0 && a.K == 4 * a.Cin && a.N % 4 == 0 && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.stride == 1 &&
+                       a.up == 0 && (a.Hin * a.Win) % 128 == 0 && a.M % (4 * a.Hin * a.Win) == 0 && a.R == nullptr &&
+                       a.zero_page != nullptr && a.w_batch_stride > 0 && !(a.splitk > 1 && a.slab),
+                   "conv3x3 sub-pixel upsample: bf16, K = 4 Cin, low-res pixels per sample %% 128 == 0, no residual, no split-K");
+        return launch<128, 160, 2, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
+    }
     SD_REQUIRE(a.K == 9 * a.Cin, "conv3x3: K must be 9*Cin");
     SD_REQUIRE(a.N % 4 == 0, "conv3x3: Cout=%d must be a multiple of 4", a.N);
     SD_REQUIRE(a.stride == 1 || a.stride == 2, "conv3x3: stride %d", a.stride);

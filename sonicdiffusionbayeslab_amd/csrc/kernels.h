@@ -46,6 +46,11 @@ struct GemmArgs {
     // contiguous 5 KiB block for the self-attention's LDS-DMA.  Needs head dim 40, hm_C % 160 == 0, hm_tok % 128 == 0.
     bf16_t* KV = nullptr;
     int hm_C = 0, hm_tok = 0;
+    // CONV, nearest-2x upsample + 3x3 conv as FOUR 2x2 convs on the low-res input (sub-pixel phases (py, px) of the output):
+    //   out[2y+py, 2x+px] = sum_{dy,dx in {0,1}} W4[ph][dy][dx] . in[y-1+py+dy, x-1+px+dx],  W4 = sums of the 3x3 taps that
+    //   read the same low-res pixel -- 4/9 of the multiply-adds, exact.  Rows are ordered (sample, phase, low-res pixel);
+    //   W holds [4 phases][Cout][Cin/64][4 taps][64] (w_batch_stride = one phase), K = 4 Cin, Hout = 2 Hin, M = 4 B Hin Win.
+    int subpix = 0;
     const float* ln_rs = nullptr;
     const float* ln_c1 = nullptr;
     int ln_np = 0;

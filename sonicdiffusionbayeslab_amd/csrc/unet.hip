@@ -116,6 +116,7 @@ struct Op {
     int stats = -1, s1 = -1, s2 = -1;
     // LayerNorm fold: rs = row partials this op writes ([np][M][2] fp32); lnrs / lnnp / c1 = partials and column sums
     // this GEMM normalises with (its x1 is the un-normalised tensor, its weights carry gamma, its bias W beta + b)
+    int subpix = 0;                   // CONV3 with up: four 2x2 convs on the low-res input (GemmArgs::subpix)
     int hm = 0;                       // GEMM: q|k|v with head-major K / V (HW = tokens per sample); ATTN: K / V are head-major
     int rs = -1, lnrs = -1, lnnp = 0;
     size_t c1 = NOFF;
@@ -451,6 +452,28 @@ struct Packer {
                     o[(((size_t)oc * (I / 64) + ic / 64) * 9 + t) * 64 + (ic % 64)] =
                         f32_to_bf16_host(d[((size_t)oc * I + ic) * 9 + t]);
     }
+    // nearest-2x upsample + 3x3 conv == four 2x2 convs on the low-res input (GemmArgs::subpix): phase (py, px) of the output
+    // reads low-res rows {y - 1 + py, y + py}; the 3x3 taps that land on the same low-res pixel are summed (in fp32):
+    //   py = 0: row 0 <- tap row 0, row 1 <- tap rows 1 + 2;   py = 1: row 0 <- tap rows 0 + 1, row 1 <- tap row 2
+    // OIHW -> [4 phases][O][I/64][4 taps (dy, dx)][64]
+    void conv3_subpixel(const std::string& n, int O, int I) {
+        const auto& d = P(n);
+        const size_t per = (size_t)O * I * 4;
+        size_t off = alloc(n + ".sub", 4 * per * 2);
+        unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+        auto lo = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2); };      // first 3x3 tap of 2x2 tap t
+        auto hi = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2); };      // last one
+        for (int ph = 0; ph < 4; ++ph)
+            for (int oc = 0; oc < O; ++oc)
+                for (int ic = 0; ic < I; ++ic)
+                    for (int t = 0; t < 4; ++t) {
+                        const int py = ph >> 1, px = ph & 1, dy = t >> 1, dx = t & 1;
+                        float acc = 0.f;
+                        for (int ty = lo(py, dy); ty <= hi(py, dy); ++ty)
+                            for (int tx = lo(px, dx); tx <= hi(px, dx); ++tx) acc += d[((size_t)oc * I + ic) * 9 + ty * 3 + tx];
+                        o[ph * per + (((size_t)oc * (I / 64) + ic / 64) * 4 + t) * 64 + (ic % 64)] = f32_to_bf16_host(acc);
+                    }
+    }
     void conv3_ohwi(const std::string& n, int O, int I) {  // OIHW -> [O][tap][I] (conv_out kernel)
         const auto& d = P(n);
         size_t off = alloc(n, d.size() * 2);
@@ -759,6 +782,7 @@ int pack_all(sd_unet* u) {
         const int lev = nl - 1 - i, cu = c.block_out_channels[lev];
         const std::string up = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
         pk.conv3(up + "weight", cu, cu); pk.f32(up + "bias");
+        pk.conv3_subpixel(up + "weight", cu, cu);
     }
     pk.f32("conv_norm_out.weight"); pk.f32("conv_norm_out.bias");
     pk.conv3_ohwi("conv_out.weight", c.out_channels, c0); pk.f32("conv_out.bias");
@@ -866,6 +890,17 @@ struct Builder {
         o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
         if (fq) { o.dt = 1; o.Cin = pad128(cin); o.K = 9 * o.Cin; o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = u->s_norm; }
         else o.w = W(w);
+        // upsampler: nearest-2x + 3x3 as four 2x2 convs on the low-res input, 4/9 of the multiply-adds (SD_CONV_SUBPIXEL=0: off)
+        static const bool subpix_off = getenv("SD_CONV_SUBPIXEL") && atoi(getenv("SD_CONV_SUBPIXEL")) == 0;
+        if (up && !fq && !subpix_off && u->kind == 0 && stride == 1 && r < 0 && b2t < 0 && (hin * hin) % 128 == 0 &&
+            u->woff.count(w + ".sub")) {
+            o.subpix = 1; o.K = 4 * cin; o.Kalg = 4 * cin;        // (Kalg: the EXECUTED multiply-adds, 4/9 of the 3x3 form)
+            o.w = W(w + ".sub"); o.splitk = 1;
+            o.out = tensor((size_t)o.M * cout * 2);
+            want_stats(o, o.M, cout);
+            push(o);
+            return o.out;
+        }
         o.splitk = sd_conv3x3_splitk(o.M, o.N, o.Cin, hin, hin, stride, up, o.dt);
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * o.M * o.N * 4);
         o.out = tensor((size_t)o.M * cout * 2);
@@ -1352,6 +1387,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
             if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
             a.stats = (float*)T(o.stats);
+            if (o.subpix) { a.subpix = 1; a.up = 0; a.w_batch_stride = (long)o.N * 4 * o.Cin; }
             return sd_launch_conv3x3(a, stream);
         }
         case OP_GEMM: {
@@ -1829,6 +1865,19 @@ extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const f
         a.slab = (float*)op_scratch((size_t)a.splitk * a.M * a.N * 4);
         SD_REQUIRE(a.slab, "sd_op_conv3x3: cannot allocate split-K scratch");
     }
+    return sd_launch_conv3x3(a, (hipStream_t)stream);
+}
+
+// nearest-2x upsample + 3x3 conv computed as four 2x2 convs on the low-res input (GemmArgs::subpix); W4 =
+// [4 phases][Cout][Cin/64][4 taps][64] with the 3x3 taps that read the same low-res pixel summed (Packer::conv3_subpixel)
+extern "C" int sd_op_conv3x3_upsample_subpixel(void* stream, const void* X, const void* W4, const float* bias, void* Y, int B,
+                                               int Hin, int Win, int Cin, int Cout) {
+    if (ensure_zero_page()) return -2;
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W4; a.bias = bias; a.C = (bf16_t*)Y; a.ldc = Cout;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = 1; a.up = 0; a.Hout = 2 * Hin; a.Wout = 2 * Win;
+    a.M = 4 * B * Hin * Win; a.N = Cout; a.K = 4 * Cin; a.K1 = a.K; a.zero_page = g_zero_page; a.splitk = 1;
+    a.subpix = 1; a.w_batch_stride = (long)Cout * 4 * Cin;
     return sd_launch_conv3x3(a, (hipStream_t)stream);
 }
 

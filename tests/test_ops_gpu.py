@@ -146,6 +146,30 @@ def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
     assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100)])
+def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
+    """Upsample2D = nearest 2x + 3x3 conv, computed as four 2x2 convs on the low-res input (one per output phase) with
+    summed taps: the same linear map with 4/9 of the multiply-adds; against interpolate + conv2d."""
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}                       # phase -> 3x3 taps behind 2x2 tap 0 / 1
+    w4 = torch.zeros(4, Cout, Cin, 2, 2)
+    for py in (0, 1):
+        for px in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w4[py * 2 + px, :, :, dy, dx] = w[:, :, rows[py][dy]][:, :, :, rows[px][dx]].sum((2, 3))
+    w4p = w4.permute(0, 1, 3, 4, 2).reshape(4, Cout, 4, Cin // 64, 64).permute(0, 1, 3, 2, 4).contiguous()
+    xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    out = torch.full((B, 2 * H, 2 * H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_conv3x3_upsample_subpixel(stream(), P(xd), P(w4p, torch.bfloat16), P(b), P(out), B, H, H, Cin, Cout))
+    torch.cuda.synchronize()
+    assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
+
+
 @pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [
     (2, 256, 320, 0, 1, 1e-5),
     (2, 64, 640, 320, 1, 1e-5),     # concat 960: groups of 30 straddle the tensor boundary
