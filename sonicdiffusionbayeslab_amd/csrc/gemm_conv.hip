@@ -830,9 +830,14 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
     SD_REQUIRE(a.Cin % 64 == 0, "conv3x3: Cin=%d must be a multiple of 64", a.Cin);
     if (a.subpix) {     // nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-res input (GemmArgs::subpix)
         SD_REQUIRE(a.dt == 0 && a.K == 4 * a.Cin && a.N % 4 == 0 && a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.stride == 1 &&
-                       a.up == 0 && (a.Hin * a.Win) % 128 == 0 && a.M % (4 * a.Hin * a.Win) == 0 && a.R == nullptr &&
+                       a.up == 0 && (a.Hin * a.Win) % 64 == 0 && a.M % (4 * a.Hin * a.Win) == 0 && a.R == nullptr &&
                        a.zero_page != nullptr && a.w_batch_stride > 0 && !(a.splitk > 1 && a.slab),
-                   "conv3x3 sub-pixel upsample: bf16, K = 4 Cin, low-res pixels per sample %% 128 == 0, no residual, no split-K");
+                   "conv3x3 sub-pixel upsample: bf16, K = 4 Cin, low-res pixels per sample %% 64 == 0, no residual, no split-K");
+        // a tile must not straddle two phases: 64-row tiles for 8x8 inputs (no GroupNorm block statistics on that tile)
+        if ((a.Hin * a.Win) % 128 != 0) {
+            SD_REQUIRE(!a.stats, "conv3x3 sub-pixel upsample: block statistics need low-res pixels per sample %% 128 == 0");
+            return launch<64, 160, 2, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
+        }
         return launch<128, 160, 2, 2, 2, AMODE_CONV, EPI_STD>(a, stream);
     }
     SD_REQUIRE(a.K == 9 * a.Cin, "conv3x3: K must be 9*Cin");

@@ -892,12 +892,12 @@ struct Builder {
         else o.w = W(w);
         // upsampler: nearest-2x + 3x3 as four 2x2 convs on the low-res input, 4/9 of the multiply-adds (SD_CONV_SUBPIXEL=0: off)
         static const bool subpix_off = getenv("SD_CONV_SUBPIXEL") && atoi(getenv("SD_CONV_SUBPIXEL")) == 0;
-        if (up && !fq && !subpix_off && u->kind == 0 && stride == 1 && r < 0 && b2t < 0 && (hin * hin) % 128 == 0 &&
+        if (up && !fq && !subpix_off && u->kind == 0 && stride == 1 && r < 0 && b2t < 0 && (hin * hin) % 64 == 0 &&
             u->woff.count(w + ".sub")) {
             o.subpix = 1; o.K = 4 * cin; o.Kalg = 4 * cin;        // (Kalg: the EXECUTED multiply-adds, 4/9 of the 3x3 form)
             o.w = W(w + ".sub"); o.splitk = 1;
             o.out = tensor((size_t)o.M * cout * 2);
-            want_stats(o, o.M, cout);
+            if ((hin * hin) % 128 == 0) want_stats(o, o.M, cout);     // (8x8 inputs run on 64-row tiles: no block statistics)
             push(o);
             return o.out;
         }

@@ -146,7 +146,7 @@ def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
     assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100)])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100), (5, 8, 128, 320)])
 def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
     """Upsample2D = nearest 2x + 3x3 conv, computed as four 2x2 convs on the low-res input (one per output phase) with
     summed taps: the same linear map with 4/9 of the multiply-adds; against interpolate + conv2d."""
