@@ -12,8 +12,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <thread>
@@ -126,6 +128,36 @@ struct Op {
     Wrap wraps[3];
 };
 
+// Host staging buffer of the packed weights: ONE anonymous mapping reserved up front and populated by the kernel in bulk
+// (MAP_POPULATE, transparent huge pages where available).  A std::vector paid ~20 us per 4 KiB first-touch fault here:
+// 11-19 s of a 22 s finalize for the 2.3 GB UNet blob.
+struct HostBlob {
+    unsigned char* p = nullptr;
+    size_t n = 0, cap = 0;
+    unsigned char* data() { return p; }
+    const unsigned char* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    bool reserve(size_t bytes) {
+        if (bytes <= cap) return true;
+        void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);
+        if (q == MAP_FAILED) return false;
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        if (p) { memcpy(q, p, n); munmap(p, cap); }
+        p = (unsigned char*)q; cap = bytes;
+        return true;
+    }
+    void resize(size_t bytes) {             // (new bytes are zero: fresh anonymous pages)
+        if (bytes > cap && !reserve(std::max(bytes, cap * 2))) { fprintf(stderr, "libsdhip: cannot map %zu bytes of host staging\n", bytes); abort(); }
+        n = bytes;
+    }
+    void release() { if (p) munmap(p, cap); p = nullptr; n = cap = 0; }
+    ~HostBlob() { release(); }
+    HostBlob() = default;
+    HostBlob(const HostBlob&) = delete;
+    HostBlob& operator=(const HostBlob&) = delete;
+};
+
 struct Tn {
     size_t bytes = 0;
     int def = -1, last = -1;
@@ -161,7 +193,7 @@ struct sd_unet {
     std::vector<ParamSpec> params;
     std::unordered_map<std::string, int> pindex;
     std::unordered_map<std::string, size_t> woff;  // packed item -> byte offset into dweights
-    std::vector<unsigned char> hblob;              // host staging of the packed blob
+    HostBlob hblob;                                // host staging of the packed blob
     char* dweights = nullptr;
     bool finalized = false;
     bool debug_taps = false;
@@ -379,6 +411,39 @@ inline unsigned char f32_to_e4m3_host(float f) {
     return sign | (unsigned char)((biased << 3) | q);
 }
 
+// host-side packing runs over up to 8 threads (0.86 G parameters: the single-threaded pack took ~20 s)
+template <class F>
+static void parallel_for(long n, F&& body) {
+    const int nt = (int)std::max(1l, std::min<long>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), n));
+    if (nt == 1) { body(0l, n); return; }
+    std::vector<std::thread> th;
+    const long per = (n + nt - 1) / nt;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { body(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    body(0l, std::min(n, per));
+    for (auto& x : th) x.join();
+}
+// dst[i][k] += a[i] * row[k] for NB rows (the inner kernel of Packer::ff_out_merge); the AVX2 + FMA clone is picked at run
+// time (the library is built for the generic x86-64 baseline)
+template <int NB>
+__attribute__((target("avx2,fma"))) static void axpy_rows_avx2(float* const* dst, const float* a, const float* __restrict__ row, int K) {
+    for (int i = 0; i < NB; ++i) {
+        float* __restrict__ d = dst[i];
+        const float ai = a[i];
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int k = 0; k < K; ++k) d[k] += ai * row[k];
+    }
+}
+template <int NB>
+static void axpy_rows_base(float* const* dst, const float* a, const float* __restrict__ row, int K) {
+    for (int i = 0; i < NB; ++i) {
+        float* __restrict__ d = dst[i];
+        const float ai = a[i];
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int k = 0; k < K; ++k) d[k] += ai * row[k];
+    }
+}
+
+static double g_alloc_s = 0;
 struct Packer {
     sd_unet* u;
     // rows [N][K] fp32 -> e4m3 [N][Kp] (K zero padded to Kp) + one fp32 scale per row (amax / 448)
@@ -426,7 +491,9 @@ struct Packer {
     const std::vector<float>& P(const std::string& n) { return u->params[u->pindex.at(n)].data; }
     size_t alloc(const std::string& key, size_t bytes) {
         size_t off = (u->hblob.size() + 255) / 256 * 256;
+        const auto t0 = std::chrono::steady_clock::now();
         u->hblob.resize(off + bytes);
+        g_alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         u->woff[key] = off;
         return off;
     }
@@ -439,18 +506,22 @@ struct Packer {
         const auto& d = P(n);
         size_t off = alloc(n, d.size() * 2);
         unsigned short* o = (unsigned short*)(u->hblob.data() + off);
-        for (size_t i = 0; i < d.size(); ++i) o[i] = f32_to_bf16_host(d[i]);
+        const float* src = d.data();
+        parallel_for((long)d.size(), [=](long b, long e) { for (long i = b; i < e; ++i) o[i] = f32_to_bf16_host(src[i]); });
     }
     // OIHW -> [O][I/64][tap][64]: K index = (64-channel slice, tap, channel) as the conv kernel walks it
     void conv3(const std::string& n, int O, int I) {
         const auto& d = P(n);
         size_t off = alloc(n, d.size() * 2);
         unsigned short* o = (unsigned short*)(u->hblob.data() + off);
-        for (int oc = 0; oc < O; ++oc)
-            for (int ic = 0; ic < I; ++ic)
-                for (int t = 0; t < 9; ++t)
-                    o[(((size_t)oc * (I / 64) + ic / 64) * 9 + t) * 64 + (ic % 64)] =
-                        f32_to_bf16_host(d[((size_t)oc * I + ic) * 9 + t]);
+        const float* src = d.data();
+        parallel_for(O, [=](long b, long e) {
+            for (long oc = b; oc < e; ++oc)
+                for (int ic = 0; ic < I; ++ic)
+                    for (int t = 0; t < 9; ++t)
+                        o[(((size_t)oc * (I / 64) + ic / 64) * 9 + t) * 64 + (ic % 64)] =
+                            f32_to_bf16_host(src[((size_t)oc * I + ic) * 9 + t]);
+        });
     }
     // nearest-2x upsample + 3x3 conv == four 2x2 convs on the low-res input (GemmArgs::subpix): phase (py, px) of the output
     // reads low-res rows {y - 1 + py, y + py}; the 3x3 taps that land on the same low-res pixel are summed (in fp32):
@@ -530,17 +601,17 @@ struct Packer {
         const int K4 = 4 * C, KT = 5 * C;
         std::vector<float> prod((size_t)C * K4, 0.f);
         const int nthreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
         auto work = [&](int tid) {
-            constexpr int NB = 8;                        // output rows per pass over W2
-            for (int n0 = tid * NB; n0 < C; n0 += nthreads * NB) {
-                const int nb = std::min(NB, C - n0);
+            constexpr int NB = 8;                        // output rows per pass over W2 (C is a multiple of 8)
+            for (int n0 = tid * NB; n0 + NB <= C; n0 += nthreads * NB) {
+                float* dst[NB];
+                float a[NB];
+                for (int i = 0; i < NB; ++i) dst[i] = &prod[(size_t)(n0 + i) * K4];
                 for (int c = 0; c < C; ++c) {
-                    const float* row = &w2[(size_t)c * K4];
-                    for (int i = 0; i < nb; ++i) {
-                        const float a = wpo[(size_t)(n0 + i) * C + c];
-                        float* dst = &prod[(size_t)(n0 + i) * K4];
-                        for (int k = 0; k < K4; ++k) dst[k] += a * row[k];
-                    }
+                    for (int i = 0; i < NB; ++i) a[i] = wpo[(size_t)(n0 + i) * C + c];
+                    if (avx2) axpy_rows_avx2<NB>(dst, a, &w2[(size_t)c * K4], K4);
+                    else axpy_rows_base<NB>(dst, a, &w2[(size_t)c * K4], K4);
                 }
             }
         };
@@ -1599,11 +1670,22 @@ extern "C" int sd_unet_finalize(sd_unet* u) {
     SD_REQUIRE(u, "finalize: null handle");
     SD_REQUIRE(!u->finalized, "finalize: already finalized");
     for (auto& p : u->params) SD_REQUIRE(p.loaded, "finalize: parameter '%s' was never loaded", p.name.c_str());
+    g_alloc_s = 0;
+    const auto tp0 = std::chrono::steady_clock::now();
+    {   // one reservation for the staging blob (packed weights never exceed the fp32 parameters' bytes): growing the vector
+        // piecemeal re-copied it again and again -- 19 of the 22 s a UNet finalize used to take
+        size_t total = 0;
+        for (auto& p : u->params) total += p.data.size() * 4;
+        u->hblob.reserve(total + (64u << 20));
+    }
     if (pack_all(u)) return -1;          // host-only: repacks / quantises into the staging blob (runs without a GPU too)
+    if (getenv("SD_PACK_TIMING"))
+        fprintf(stderr, "libsdhip: pack %.2f s (of which staging-blob growth %.2f s), %zu bytes\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count(), g_alloc_s, u->hblob.size());
     if (ensure_zero_page()) return -2;
     SD_CHECK_HIP(hipMalloc((void**)&u->dweights, u->hblob.size()));
     SD_CHECK_HIP(hipMemcpy(u->dweights, u->hblob.data(), u->hblob.size(), hipMemcpyHostToDevice));
-    std::vector<unsigned char>().swap(u->hblob);
+    u->hblob.release();
     for (auto& p : u->params) std::vector<float>().swap(p.data);
     u->finalized = true;
     return 0;
