@@ -311,7 +311,8 @@ def main():
         res["roofline"] = {"bound": "mfma",
                            "kernel": ("conv_halo_kernel<fp8> (3x3 resnet convs on v_mfma_f32_16x16x128_f8f6f4, LDS-resident input halo)"
                                       if fp8 else
-                                      "conv_halo_kernel (3x3 conv, LDS-resident input halo; 47 of the 50 conv launches of a forward)"),
+                                      "conv_halo_kernel (3x3 conv, LDS-resident input halo; the stride-1 convs of a forward: 44 of its 50 conv launches "
+                                      "-- the 3 stride-2 convs and the 3 sub-pixel upsamplers run on the implicit-GEMM kernel, kernel_breakdown.conv3x3_gemm)"),
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": None if fp8 else conv_traffic_bytes(),
                            "traffic_source": None if fp8 else TRAFFIC_SOURCE,

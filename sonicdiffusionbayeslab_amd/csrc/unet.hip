@@ -1868,7 +1868,10 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
         const Op& o = pl->ops[which[j]];
         double fl, by;
         op_work(o, &fl, &by);
-        const int kd = o.kind == OP_XATTN ? 18 : o.kind == OP_REPLICATE ? 19 : (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
+        // (20: the convs that run on the implicit-GEMM kernel -- stride 2 and the sub-pixel upsamplers -- apart from the halo kernel's)
+        const int kd = o.kind == OP_XATTN ? 18 : o.kind == OP_REPLICATE ? 19 :
+                       (o.kind == OP_CONV3 && !o.dt && (o.subpix || o.stride != 1)) ? 20 :
+                       (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
         kind_ms[kd] += ms; kind_launches[kd] += 1; kind_flops[kd] += fl; kind_bytes[kd] += by;
     }
     for (auto e : ev) (void)hipEventDestroy(e);
