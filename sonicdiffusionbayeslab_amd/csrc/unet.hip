@@ -34,7 +34,7 @@ void sd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sd_last_error(void) { return g_err; }
-extern "C" int sd_abi_version(void) { return 2; }   // 2: sd_unet_config.weight_dtype, fp8 operator entry points
+extern "C" int sd_abi_version(void) { return 3; }   // 2: sd_unet_config.weight_dtype, fp8 entry points; 3: round-2 fusion entry points
 
 static void* g_zero_page = nullptr;
 // grow-only device scratch for the operator-level entry points (tests / micro-benchmarks only;

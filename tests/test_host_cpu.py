@@ -76,7 +76,7 @@ def test_abi_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sd_hip.h but not exported"
     assert set(names) == set(_lib._SIGS), set(names) ^ set(_lib._SIGS)
-    assert lib.sd_abi_version() == 2
+    assert lib.sd_abi_version() == 3
 
 
 def test_param_enumeration_matches_library():
