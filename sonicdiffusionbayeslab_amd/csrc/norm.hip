@@ -228,17 +228,31 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     auto src = [&](int p, int c) -> const bf16_t* {
         return c < a.C1 ? a.x1 + (base + p) * a.C1 + c : a.x2 + (base + p) * a.C2 + (c - a.C1);
     };
-    // unit i = tid + 256 j  <->  (pixel p, unit k): stepped incrementally, no division in the loops
+    // unit i = tid + 256 j  <->  (pixel p, unit k): stepped incrementally, no division in the loops.  The group's values
+    // (<= 10 units of 4 channels per thread) are loaded ONCE, all loads in flight together, and stay in registers.
+    constexpr int MAXU = 10;                         // 10 240 values / 4 per unit / 256 threads
     const int p0 = tid / upp, k0 = tid - p0 * upp, dp = 256 / upp, dk = 256 - dp * upp;
+    u32x2 vals[MAXU];
+    int pj[MAXU], kj[MAXU];
+    {
+        int p = p0, k = k0;
+#pragma unroll
+        for (int j = 0; j < MAXU; ++j) {
+            pj[j] = p; kj[j] = k;
+            const bool live = tid + 256 * j < total;
+            const int pc = live ? p : 0, kc = live ? k : 0;              // unconditional load from a valid address
+            vals[j] = *(const u32x2*)src(pc, grp * cpg + kc * 4);
+            p += dp; k += dk;
+            if (k >= upp) { k -= upp; ++p; }
+        }
+    }
     float s = 0.f, q = 0.f;
-    for (int i = tid, p = p0, k = k0; i < total; i += 256) {
-        const int c = grp * cpg + k * 4;
-        const u32x2 v = *(const u32x2*)src(p, c);
-        p += dp; k += dk;
-        if (k >= upp) { k -= upp; ++p; }
-        const float f0 = bflo(v[0]), f1 = bfhi(v[0]), f2 = bflo(v[1]), f3 = bfhi(v[1]);
-        s += (f0 + f1) + (f2 + f3);
-        q += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+        const bool live = tid + 256 * j < total;
+        const float f0 = bflo(vals[j][0]), f1 = bfhi(vals[j][0]), f2 = bflo(vals[j][1]), f3 = bfhi(vals[j][1]);
+        s += live ? (f0 + f1) + (f2 + f3) : 0.f;
+        q += live ? (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3) : 0.f;
     }
     s = wave_sum(s);
     q = wave_sum(q);
@@ -249,17 +263,17 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     const float cnt = (float)a.HW * (float)cpg;
     const float mean = ts / cnt;
     const float rstd = rsqrtf(fmaxf(tq / cnt - mean * mean, 0.f) + a.eps);
-    for (int i = tid, pp = p0, k = k0; i < total; i += 256) {
-        const int p = pp, c = grp * cpg + k * 4;
-        const u32x2 v = *(const u32x2*)src(p, c);
-        pp += dp; k += dk;
-        if (k >= upp) { k -= upp; ++pp; }
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+        if (tid + 256 * j >= total) break;
+        const int p = pj[j], c = grp * cpg + kj[j] * 4;
+        const u32x2 v = vals[j];
         const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
         float f[4] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f[j] = (f[j] - mean) * rstd * gm[j] + bt[j];
-            if (a.silu) f[j] = silu_f(f[j]);
+        for (int jj = 0; jj < 4; ++jj) {
+            f[jj] = (f[jj] - mean) * rstd * gm[jj] + bt[jj];
+            if (a.silu) f[jj] = silu_f(f[jj]);
         }
         if (a.out_fp8) {
             *(unsigned*)((char*)a.y + (base + p) * a.Cpad + c) =
