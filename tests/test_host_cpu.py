@@ -384,6 +384,16 @@ def test_finalize_packs_weights_on_the_host(dtype):
         assert (got - want).abs().max() <= 2.0 ** -8 * want.abs().max()                  # one bf16 rounding of an fp32 product
         assert torch.equal(got[:, 1280:], wpo.float().bfloat16().float())
         assert torch.allclose(packed(a + "ff_out.bias", 320 * 4, torch.float32), (wpo @ b2 + bpo).float(), rtol=1e-5, atol=1e-6)
+        # upsampler as four 2x2 sub-pixel convs: [phase][O][I/64][tap][64], 3x3 taps that read the same low-res pixel summed
+        wu = sd["up_blocks.0.upsamplers.0.conv.weight"].float()                       # [640, 640, 3, 3]
+        rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+        got = packed("up_blocks.0.upsamplers.0.conv.weight.sub", 4 * 640 * 640 * 4 * 2, torch.bfloat16).view(4, 640, 10, 4, 64)
+        for py in (0, 1):
+            for px in (0, 1):
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        want = wu[:, :, rows[py][dy]][:, :, :, rows[px][dx]].sum((2, 3)).bfloat16()      # [O, I]
+                        assert torch.equal(got[py * 2 + px, :, :, dy * 2 + dx, :].reshape(640, 640), want)
         # LayerNorm folded into q|k|v: rows bf16(W gamma), c1 = sum of the ROUNDED row, c2 = W beta
         g1, be1 = sd[t + "norm1.weight"].float(), sd[t + "norm1.bias"].double()
         rows = torch.cat([sd[t + f"attn1.to_{x}.weight"] for x in "qkv"]).float()
