@@ -231,6 +231,10 @@ int sd_op_xattn_fused_rowstats(void* stream, const void* X, const void* R, void*
                                const float* bias, int M, int C, int rows_per_sample, int L, float* rowstats);
 int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                       const float* bias, int M, int C, int rows_per_sample, int L);
+/* diagnostic twin (tools/xattn_stamps.py; no reference counterpart): same result, and the kernel stores 8 s_memtime
+ * stamps per workgroup to `stamps` (caller-owned device memory, 8 * (M / 128) * slices 64-bit words) */
+int sd_op_xattn_fused_stamps(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                             const float* bias, int M, int C, int rows_per_sample, int L, unsigned long long* stamps);
 
 /* ---- fp8-e4m3 operand path (SD_DTYPE_FP8_E4M3), operator level ------------------------------------------------
  * X, W hold OCP e4m3 bytes; K / Cin count fp8 elements and are multiples of 128 (zero padded); wscale [N] fp32 is the

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <new>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -148,7 +149,8 @@ struct HostBlob {
         return true;
     }
     void resize(size_t bytes) {             // (new bytes are zero: fresh anonymous pages)
-        if (bytes > cap && !reserve(std::max(bytes, cap * 2))) { fprintf(stderr, "libsdhip: cannot map %zu bytes of host staging\n", bytes); abort(); }
+        // a failed mapping surfaces as an error of sd_unet_finalize (which catches this), never as an abort of the host process
+        if (bytes > cap && !reserve(std::max(bytes, cap * 2))) throw std::bad_alloc();
         n = bytes;
     }
     void release() { if (p) munmap(p, cap); p = nullptr; n = cap = 0; }
@@ -896,7 +898,10 @@ struct Builder {
         int np = 0;
         if (o.kind == OP_GEMM && o.epi == 0 && o.splitk == 1 && !o.out_fp8 && o.N == C && o.M == M && o.ldc_o == 0) np = (C + 159) / 160 * 2;
         else if (o.kind == OP_XATTN && o.N == C && o.M == M) np = 2 * sd_xattn_slices(M, C);
-        if (!ln_fold || np == 0) return 0;
+        // the consumer's preconditions (gemm_conv.hip::check_ln): K = C >= 128 (two K tiles: with one, the c1 | c2 LDS-DMA is
+        // never waited for), at most 16 partials per row, 128-row tiles -- otherwise the plan keeps the separate LayerNorm
+        static const bool big_tiles = getenv("SD_GEMM_BIG") != nullptr;
+        if (!ln_fold || np == 0 || np > 16 || C < 128 || big_tiles) return 0;
         o.rs = rs = tensor((size_t)np * M * 2 * 4);
         return np;
     }
@@ -1672,13 +1677,21 @@ extern "C" int sd_unet_finalize(sd_unet* u) {
     for (auto& p : u->params) SD_REQUIRE(p.loaded, "finalize: parameter '%s' was never loaded", p.name.c_str());
     g_alloc_s = 0;
     const auto tp0 = std::chrono::steady_clock::now();
-    {   // one reservation for the staging blob (packed weights never exceed the fp32 parameters' bytes): growing the vector
-        // piecemeal re-copied it again and again -- 19 of the 22 s a UNet finalize used to take
+    {   // one reservation for the staging blob: growing it piecemeal re-copied it again and again (19 of the 22 s a UNet
+        // finalize used to take).  In AGGREGATE the packed blob (2.26 GB for the bf16 UNet: bf16 weights, some of them twice --
+        // sub-pixel upsamplers, *.ln copies, ff_out, attn2.to_q.T) stays below the fp32 parameters' bytes (3.44 GB), so this
+        // rarely grows; if it has to, HostBlob::resize re-maps at twice the size.
         size_t total = 0;
         for (auto& p : u->params) total += p.data.size() * 4;
-        u->hblob.reserve(total + (64u << 20));
+        SD_REQUIRE(u->hblob.reserve(total + (64u << 20)), "finalize: cannot map %zu bytes of host staging memory", total + (64u << 20));
     }
-    if (pack_all(u)) return -1;          // host-only: repacks / quantises into the staging blob (runs without a GPU too)
+    try {
+        if (pack_all(u)) return -1;      // host-only: repacks / quantises into the staging blob (runs without a GPU too)
+    } catch (const std::bad_alloc&) {
+        u->hblob.release();
+        sd_set_error("finalize: out of host memory while packing the weights");
+        return -2;
+    }
     if (getenv("SD_PACK_TIMING"))
         fprintf(stderr, "libsdhip: pack %.2f s (of which staging-blob growth %.2f s), %zu bytes\n",
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count(), g_alloc_s, u->hblob.size());
@@ -2164,6 +2177,17 @@ extern "C" int sd_op_xattn_fused(void* stream, const void* X, const void* R, voi
     XattnArgs a;
     a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
     a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L;
-    if (const char* e = getenv("SD_XATTN_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostic build of the op
+    return sd_launch_xattn_fused(a, (hipStream_t)stream);
+}
+
+// diagnostic twin of sd_op_xattn_fused (tools/xattn_stamps.py): the kernel additionally stores 8 s_memtime stamps per
+// workgroup to `stamps` (device memory, 8 * (M / 128) * slices 64-bit words, owned by the caller)
+extern "C" int sd_op_xattn_fused_stamps(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                                        const float* bias, int M, int C, int rows_per_sample, int L, unsigned long long* stamps) {
+    SD_REQUIRE(stamps, "sd_op_xattn_fused_stamps: null stamp buffer");
+    SD_REQUIRE(sd_xattn_fused_applicable(rows_per_sample, C, 8, L), "sd_op_xattn_fused_stamps: shape not supported");
+    XattnArgs a;
+    a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
+    a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L; a.stamps = stamps;
     return sd_launch_xattn_fused(a, (hipStream_t)stream);
 }

@@ -8,10 +8,13 @@ hot-path scope; results go to stdout as JSON lines.
 Multi-GPU (new relative to the single-device reference): launched under
 ``torch.distributed.run`` (one process per GPU), every prompt batch is split contiguously over the ranks,
 each rank samples its shard on its own weight replica, and ONE all-gather per batch returns the results to
-every rank.  The global initial latents (and the LCM step noise) come from the shared seeded CPU generator and
-are sliced per rank, so the inputs of every image are the same for every world size."""
+every rank.  Every Gaussian a pipeline call consumes (initial latents, LCM re-noising, SDE-DPM-Solver noise, eta > 0, the
+variant pipelines' draws) is drawn for the GLOBAL batch from the shared seeded CPU generator, in the single-process order,
+and sliced per rank (``dist.randn`` / ``dist.shard_draws``), so the inputs of every image are the same for every world
+size -- also for the stochastic samplers, ragged shards and ranks without a prompt."""
 from __future__ import annotations
 
+import contextlib
 import json
 from abc import ABC, abstractmethod
 from collections import defaultdict
@@ -98,41 +101,26 @@ class BaseMethod(ABC):
             if limit is not None and idx >= limit:
                 break
             prompts = list(batch["prompt"])
-            kw = dict(call_kwargs)
-            if self.world > 1:
-                lo, hi = sdist.shard_range(len(prompts), self.rank, self.world)
-                kw.update(self._global_draws(len(prompts), lo, hi, kw))
-                local_prompts = prompts[lo:hi]
-            else:
-                local_prompts = prompts
+            sharded = sdist.active()
+            lo, hi = sdist.shard_range(len(prompts), self.rank, self.world) if sharded else (0, len(prompts))
+            local_prompts = prompts[lo:hi]
             if len(local_prompts) > 0:
-                result, seconds, x0_preds = self.model(local_prompts, guidance_scale=guidance_scale,
-                                                       generator=self.generator, output_type=out_type, **kw)
+                # every Gaussian of the call (initial latents, per-step noise of the stochastic samplers) is drawn for the
+                # GLOBAL batch from the shared generator and sliced: dist.randn inside dist.shard_draws
+                with (sdist.shard_draws(len(prompts), lo, hi) if sharded else contextlib.nullcontext()):
+                    result, seconds, x0_preds = self.model(local_prompts, guidance_scale=guidance_scale,
+                                                           generator=self.generator, output_type=out_type, **call_kwargs)
                 local = result.images
             else:                       # more ranks than prompts in a ragged last batch
                 local, seconds = self._empty_result(out_type), 0.0
-            if self.world > 1:          # the ONE data-path collective; the slowest rank's loop time rides along
-                local, seconds = sdist.gather_latents(local, self.world, len(prompts), seconds=seconds)
+            if sharded:                 # the ONE data-path collective; the slowest rank's loop time rides along (and, when a
+                                        # rank had no prompt and therefore drew nothing, rank 0's generator state)
+                local, seconds = sdist.gather_latents(local, self.world, len(prompts), seconds=seconds,
+                                                      generator=self.generator)
             host = local.cpu()
             images.extend(host[i] for i in range(host.shape[0]))
             self.time_metric.update(seconds, batch_size)                 # configured size, as :161
         return images, x0_preds
-
-    def _global_draws(self, n: int, lo: int, hi: int, kw: dict) -> dict:
-        """Explicit ``latents=`` (and LCM ``step_noise=``) of this rank's shard, cut from the GLOBAL draws of the
-        shared generator -- in the order the single-process run consumes it: initial latents of the whole batch
-        (``prepare_latents``), then one Gaussian of the whole batch per re-noising step (``LCMScheduler.step``)."""
-        ucfg = self.model.unet_config
-        shape = (n, ucfg.in_channels, ucfg.sample_size, ucfg.sample_size)
-        lat = torch.randn(shape, generator=self.generator, dtype=torch.float32)
-        out = {"latents": lat[lo:hi].clone()}
-        sch = self.model.scheduler
-        steps = kw.get("num_inference_steps")
-        if hasattr(sch, "config") and "timestep_scaling" in sch.config and steps:
-            noise = [torch.randn(shape, generator=self.generator, dtype=torch.float32)[lo:hi] for _ in range(steps - 1)]
-            if noise:
-                out["step_noise"] = torch.stack(noise).to(self.device)
-        return out
 
     def _empty_result(self, out_type: str) -> torch.Tensor:
         ucfg = self.model.unet_config

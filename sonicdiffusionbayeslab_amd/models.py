@@ -30,6 +30,7 @@ from typing import Callable, List, Optional, Union
 
 import torch
 
+from . import dist as sdist
 from .registry import models_registry
 from .schedulers import PNDMConfigStub
 from .unet import CACHE_FULL_AND_STORE, CACHE_OFF, CACHE_SKIP, HipUNet2DConditionModel
@@ -211,8 +212,7 @@ class StableDiffusionModel:
     def prepare_latents(self, batch_size, num_channels, height, width, device, generator, latents=None):
         shape = (batch_size, num_channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
         if latents is None:
-            gdev = generator.device if generator is not None else torch.device("cpu")
-            latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
+            latents = sdist.randn(shape, generator)      # (the global batch's draw, sliced, under a sharded harness call)
         latents = latents.to(device, torch.float32)
         return (latents * self.scheduler.init_noise_sigma).contiguous()
 

@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import dist as sdist
 from .registry import schedulers_registry
 
 # runwayml/stable-diffusion-v1-5 scheduler/scheduler_config.json (PNDM) + the defaults PNDM stores;
@@ -369,8 +370,7 @@ class DPMSolverScheduler(_FusedStepScheduler):
         z = None
         if c.algorithm_type.startswith("sde-"):        # src/schedulers.py:134-147
             if variance_noise is None:
-                gdev = generator.device if generator is not None else x.device
-                variance_noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=torch.float32)
+                variance_noise = sdist.randn(x.shape, generator)
             z = self._prep(variance_noise.to(x.device))
         prev, x0, m0 = self._launch(self._prep(model_output), cfg, guidance_scale, x, m1, m2, z,
                                     (px, pe, p1, p2, pn, yx, ye, mx, me), want_y2=True, want_m=True)
@@ -431,8 +431,7 @@ class LCMScheduler(_FusedStepScheduler):
             coef, z = (yx, ye, 0, 0, 0, yx, ye, 0, 0), None
         else:
             if noise is None:
-                gdev = generator.device if generator is not None else x.device
-                noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=torch.float32)
+                noise = sdist.randn(x.shape, generator)
             z = self._prep(noise.to(x.device))
             coef = (math.sqrt(ap) * yx, math.sqrt(ap) * ye, 0, 0, math.sqrt(1.0 - ap), yx, ye, 0, 0)
         prev, den, _ = self._launch(self._prep(model_output), cfg, guidance_scale, x, None, None, z, coef)

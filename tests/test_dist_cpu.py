@@ -71,30 +71,31 @@ class _StubPipeline:
         return self
 
     def __call__(self, prompts, num_inference_steps=3, guidance_scale=7.5, generator=None, output_type="latent",
-                 latents=None, step_noise=None, **kw):
+                 latents=None, **kw):
+        from sonicdiffusionbayeslab_amd import dist as sdist
         n = len(prompts)
         if latents is None:
-            latents = torch.randn((n, 4, 8, 8), generator=generator)
+            latents = sdist.randn((n, 4, 8, 8), generator)           # what prepare_latents does
         out = latents.clone()
         lcm = "timestep_scaling" in self.scheduler.config
-        for i in range(num_inference_steps - 1 if lcm else 0):
-            z = step_noise[i].cpu() if step_noise is not None else torch.randn((n, 4, 8, 8), generator=generator)
+        for i in range(num_inference_steps - 1 if lcm else 0):       # a stochastic sampler: one Gaussian per step
+            z = sdist.randn((n, 4, 8, 8), generator)                 # (LCMScheduler / sde-DPM-Solver step_fused)
             out = out * 0.5 + z
         key = torch.tensor([float(sum(map(ord, p)) % 97) for p in prompts]).view(n, 1, 1, 1)
         self.calls.append(n)
         return _StubOut(out + key), 0.25 + 0.01 * n, [out[0:1]]
 
 
-def _harness_worker(rank, world, port, lcm, nprompts, q):
+def _harness_worker(rank, world, port, lcm, nprompts, batch, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SD_DIST_BACKEND="gloo")
-    q.put((rank,) + _harness_run(lcm, nprompts))
+    q.put((rank,) + _harness_run(lcm, nprompts, batch))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _harness_run(lcm, nprompts):
+def _harness_run(lcm, nprompts, batch=5):
     from sonicdiffusionbayeslab_amd.config import _wrap
     from sonicdiffusionbayeslab_amd.experiments.base_experiment import BaseMethod
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -111,18 +112,18 @@ def _harness_run(lcm, nprompts):
 
     conf = _wrap({"experiment_name": "stub", "experiment": {"method": "stub", "seed": 29},
                   "dataset": {"img_dataset": "", "prompts": os.path.join(root, "data", "dataset", "img2annotations_test.json")},
-                  "inference": {"batch_size": 5, "batch_count": (nprompts + 4) // 5, "output_type": "latent"}})
+                  "inference": {"batch_size": batch, "batch_count": (nprompts + batch - 1) // batch, "output_type": "latent"}})
     m = M(conf)
     m.test_dataset.image_files = m.test_dataset.image_files[:nprompts]
-    images, _ = m.generate(m.test_dataset.batches(5), 3, 5, guidance_scale=0.0 if lcm else 7.5)
+    images, _ = m.generate(m.test_dataset.batches(batch), 3, batch, guidance_scale=0.0 if lcm else 7.5)
     return torch.stack(images), float(m.time_metric.compute()), list(m.model.calls)
 
 
-def _harness_world2(lcm, nprompts):
+def _harness_world2(lcm, nprompts, batch=5):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_harness_worker, args=(r, 2, port, lcm, nprompts, q)) for r in range(2)]
+    ps = [ctx.Process(target=_harness_worker, args=(r, 2, port, lcm, nprompts, batch, q)) for r in range(2)]
     [p.start() for p in ps]
     outs = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
     [p.join(60) for p in ps]
@@ -131,11 +132,13 @@ def _harness_world2(lcm, nprompts):
 
 
 def test_generate_shards_batches_and_gathers_like_single_process():
-    for lcm, nprompts in ((False, 10), (True, 7), (False, 6)):      # even split, ragged batches, a rank with 0 prompts
+    # even split; a stochastic sampler (a Gaussian per step: LCM / sde-DPM-Solver) over ragged batches; a rank with 0
+    # prompts; a stochastic sampler with a prompt-less rank in EVERY batch (its generator must follow rank 0's)
+    for lcm, nprompts, batch in ((False, 10, 5), (True, 7, 5), (False, 6, 5), (True, 6, 5), (True, 3, 1)):
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             os.environ.pop(k, None)
-        want, t1, calls1 = _harness_run(lcm, nprompts)              # world 1, this process
-        outs = _harness_world2(lcm, nprompts)
+        want, t1, calls1 = _harness_run(lcm, nprompts, batch)       # world 1, this process
+        outs = _harness_world2(lcm, nprompts, batch)
         for r in (0, 1):
             got, t2, calls = outs[r]
             assert torch.equal(got, want), (lcm, nprompts, r)

@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_method(config_name, nprompts, batch):
+def _run_method(config_name, nprompts, batch, overrides=None):
     """`methods_registry[...]` from its YAML on a 16x16-latent SD-1.5-width UNet; returns gathered latents."""
     from sonicdiffusionbayeslab_amd import models as M
     from sonicdiffusionbayeslab_amd.config import load_config
@@ -37,6 +37,8 @@ def _run_method(config_name, nprompts, batch):
     conf.inference.batch_size = batch
     conf.inference.batch_count = (nprompts + batch - 1) // batch
     conf.inference.output_type = "latent"
+    for k, v in (overrides or {}).items():
+        conf.experiment_params[k] = v
     m = methods_registry[conf.experiment.method](conf)
     m.test_dataset.image_files = m.test_dataset.image_files[:nprompts]
     steps = 4
@@ -46,26 +48,34 @@ def _run_method(config_name, nprompts, batch):
     return torch.stack(images), float(m.time_metric.compute())
 
 
-def _worker(rank, world, port, config_name, nprompts, batch, q):
+def _worker(rank, world, port, config_name, nprompts, batch, q, overrides=None, backend="gloo", force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), SD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(rank), SD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force:
+        os.environ["SD_DIST_FORCE_INIT"] = "1"
     import torch.distributed as dist
-    out, t = _run_method(config_name, nprompts, batch)
+    out, t = _run_method(config_name, nprompts, batch, overrides)
+    assert dist.is_initialized() and dist.get_backend() == backend and dist.get_world_size() == world
     q.put((rank, out.cpu(), t))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("config_name,nprompts,batch", [("ddim_config.yaml", 5, 5),                 # CFG, ragged 3 + 2
-                                                         ("consistency_model_config.yaml", 6, 4)])  # LCM noise, 2 batches
-def test_world2_sharded_generate_matches_single_process(config_name, nprompts, batch):
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+SDE = {"algorithm_type": "sde-dpmsolver++"}       # a Gaussian per step from the shared generator (src/schedulers.py:134-147)
+
+
+@pytest.mark.parametrize("config_name,nprompts,batch,overrides", [
+    ("ddim_config.yaml", 5, 5, None),                   # CFG, ragged 3 + 2
+    ("consistency_model_config.yaml", 6, 4, None),      # LCM noise, 2 batches
+    ("dpm_solver_config.yaml", 4, 3, SDE)])             # stochastic DPM-Solver: ragged 2 + 1, then a batch whose rank 1 is empty
+def test_world2_sharded_generate_matches_single_process(config_name, nprompts, batch, overrides):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SD_DIST_FORCE_INIT"):
         os.environ.pop(k, None)
-    want, t1 = _run_method(config_name, nprompts, batch)
+    want, t1 = _run_method(config_name, nprompts, batch, overrides)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, config_name, nprompts, batch, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, config_name, nprompts, batch, q, overrides)) for r in range(2)]
     [p.start() for p in ps]
     outs = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(2))}
     [p.join(120) for p in ps]
@@ -76,3 +86,21 @@ def test_world2_sharded_generate_matches_single_process(config_name, nprompts, b
     print(f"{config_name}: world-2 vs world-1 rel-L2 {err:.3e} over {nprompts} images")
     assert outs[0][0].shape == want.shape and err < SHARD_TOL
     assert outs[0][1] > 0 and outs[0][1] == outs[1][1]
+
+
+def test_rccl_world1_rehearsal_of_the_gather_path():
+    """RCCL itself (backend "nccl"), once, before an 8-GPU node runs it: a fresh child process with WORLD_SIZE 1 and
+    SD_DIST_FORCE_INIT=1 creates the communicator bound to its GPU (``device_id``), shards (trivially) and goes through
+    ``gather_latents`` -> ``all_gather_into_tensor`` on device memory.  Same images as the plain single-process run, bit
+    for bit (same batch, same kernels).  No scaling claim: one rank."""
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SD_DIST_FORCE_INIT"):
+        os.environ.pop(k, None)
+    want, _ = _run_method("ddim_config.yaml", 3, 3)
+    ctx = mp.get_context("spawn")            # the child touches the GPU only after it has started (no exec of a GPU process)
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), "ddim_config.yaml", 3, 3, q, None, "nccl", True))
+    p.start()
+    rank, got, t = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert got.shape == want.shape and torch.equal(got, want) and t > 0

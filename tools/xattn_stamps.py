@@ -1,5 +1,5 @@
 """Where a workgroup of the fused cross-attention kernel spends its cycles: s_memtime stamps at the phase boundaries
-(diagnostic; the stamp buffer's address is handed to the operator entry point through SD_XATTN_STAMPS).  Development tool."""
+(diagnostic; the stamp buffer is an argument of the debug entry point sd_op_xattn_fused_stamps).  Development tool."""
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,8 +28,9 @@ for _ in range(10):
     call()
 e.record(); torch.cuda.synchronize()
 print(f"B={B} hw={hw} C={C}: {s.elapsed_time(e) / 10 * 1e3:.1f} us per launch (no stamps)")
-os.environ["SD_XATTN_STAMPS"] = str(stamps.data_ptr())
-call(); torch.cuda.synchronize()
+_lib.check(lib.sd_op_xattn_fused_stamps(st, x.data_ptr(), r.data_ptr(), y.data_ptr(), at.data_ptr(), bw.data_ptr(),
+                                        bias.data_ptr(), M, C, hw, 77, stamps.data_ptr()))
+torch.cuda.synchronize()
 t = stamps.cpu().view(-1, 8)
 t = t[t[:, 5] != 0]
 names = ["phase1 pass0", "softmax0", "phase1 pass1", "softmax1", "phase2"]
