@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import contextlib
 import json
+import os
 from abc import ABC, abstractmethod
 from collections import defaultdict
 
@@ -31,7 +32,6 @@ class BaseMethod(ABC):
         self.config = config
         # one process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE); world 1 otherwise.
         # SD_DIST_BACKEND=gloo is the CPU-side rehearsal backend of the tests (ranks may then share one GPU)
-        import os
         backend = os.environ.get("SD_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         self.rank, local_rank, self.world = sdist.init_process_group(backend)
         ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -82,8 +82,18 @@ class BaseMethod(ABC):
         self.test_dataset = PromptDataset(self.config.dataset.img_dataset, self.config.dataset.prompts)
 
     def setup_metrics(self):
+        """``src/experiments/base_experiment.py:93-113``.  ``time_metric`` always; ``clip_score`` (``:96-98``) when
+        ``quality_metrics.clip_score.model_name_or_path`` is a LOCAL checkpoint directory -- a hub name is a network
+        fetch and the metric is then reported as not computable.  FID / ImageReward are not built."""
         self.metric_dict = defaultdict(list)
         self.time_metric = metrics_registry["time_metric"]()
+        self.clip_score_gen_metric = None
+        qm = self.config.get("quality_metrics", None)
+        path = qm.get("clip_score", {}).get("model_name_or_path", None) if qm else None
+        if path and os.path.isdir(str(path)):
+            self.clip_score_gen_metric = metrics_registry["clip_score"](model_name_or_path=str(path))
+        self.clip_score_source = str(path) if self.clip_score_gen_metric is not None else (
+            f"not computable offline ({path!r} is not a local directory)" if path else "not configured")
 
     def setup_loggers(self):
         self.logger = None
@@ -97,10 +107,12 @@ class BaseMethod(ABC):
         limit = self.config.inference.get("batch_count", None)
         out_type = self.config.inference.get("output_type", "pt")        # the reference hard-codes "pt" (:145)
         images, x0_preds = [], []
+        self.last_prompts = []                                           # prompt of every returned image, in order
         for idx, batch in enumerate(test_dataloader):
             if limit is not None and idx >= limit:
                 break
             prompts = list(batch["prompt"])
+            self.last_prompts.extend(prompts)
             sharded = sdist.active()
             lo, hi = sdist.shard_range(len(prompts), self.rank, self.world) if sharded else (0, len(prompts))
             local_prompts = prompts[lo:hi]
@@ -141,13 +153,31 @@ class BaseMethod(ABC):
                                       guidance_scale=guidance_scale, **call_kwargs(point))
             self.model.to("cpu")
             self.validate(f"{self.config.experiment_name}, {label(point)}",
-                          additional_values=extra(point) if extra else None, n_images=len(images))
+                          additional_values=extra(point) if extra else None, n_images=len(images),
+                          images=images, prompts=self.last_prompts)
 
-    def validate(self, name_images, additional_values=None, n_images=0):
-        """Only the hot-path metric survives: seconds / image over the loop (``time_metric``)."""
+    def clip_score(self, images, prompts, batch_size: int = 32):
+        """``validate`` of the reference for the parity metric (``:198-201``): generated images -> uint8 by
+        ``(img * 255).to(uint8)`` (truncation), CLIPScore over (image, prompt) pairs.  None when no local CLIP
+        checkpoint was configured or the run produced latents."""
+        m = self.clip_score_gen_metric
+        if m is None or not images or images[0].dim() != 3 or images[0].shape[0] != 3:
+            return None
+        m.reset()
+        for s in range(0, len(images), batch_size):
+            gen = (torch.stack(images[s:s + batch_size]) * 255).to(torch.uint8).cpu()
+            m.update(gen, prompts[s:s + batch_size])
+        return float(m.compute())
+
+    def validate(self, name_images, additional_values=None, n_images=0, images=None, prompts=None):
+        """The hot-path metric, seconds / image over the loop (``time_metric``), and -- with a local CLIP checkpoint and
+        decoded images -- the reference's parity metric ``clip_score``."""
         if additional_values:
             for k, v in additional_values.items():
                 self.metric_dict[k].append(v)
+        cs = self.clip_score(images, prompts) if (images is not None and self.rank == 0) else None
+        if cs is not None:
+            self.metric_dict["clip_score"].append(cs)
         t = float(self.time_metric.compute())
         self.metric_dict["nfe"].append(self.model.num_timesteps)
         self.metric_dict["time_metric"].append(t)
@@ -157,4 +187,4 @@ class BaseMethod(ABC):
         print(json.dumps({"experiment": self.config.experiment_name, "run": name_images, "nfe": self.model.num_timesteps,
                           "images": n_images, "time_metric_s_per_image": t,
                           "images_per_s": (1.0 / t if t > 0 else None), "weights": self.model.weights_source,
-                          "n_gpus": self.world}), flush=True)
+                          "clip_score": cs, "clip_score_model": self.clip_score_source, "n_gpus": self.world}), flush=True)

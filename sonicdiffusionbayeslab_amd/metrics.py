@@ -2,7 +2,9 @@
 (``src/metrics/metrics.py:115-131``): sum(loop seconds) / sum(batch_size) -> seconds per image.
 ``clip_score`` is the reference's parity metric (``:25-41``, ``calc_clip_score.py:13-37``); it
 needs CLIP ViT-B/16 weights that only exist as a network fetch, so it is registered but raises
-unless a LOCAL checkpoint directory is given."""
+unless a LOCAL checkpoint directory is given.  ``BaseMethod.setup_metrics`` builds it when
+``quality_metrics.clip_score.model_name_or_path`` is such a directory and ``validate`` then reports it
+(``src/experiments/base_experiment.py:96-98,198-201``)."""
 from __future__ import annotations
 
 import os
@@ -45,9 +47,11 @@ class ClipScoreMetric:
 
     @torch.no_grad()
     def update(self, images, text):
-        inp = self.processor(text=list(text), images=[i for i in images], return_tensors="pt", padding=True)
-        img = self.model.get_image_features(inp["pixel_values"])
-        txt = self.model.get_text_features(inp["input_ids"], inp["attention_mask"])
+        inp = self.processor(text=list(text), images=[i for i in images], return_tensors="pt", padding=True, truncation=True)
+        # (transformers 4.48 returns the projected embedding itself, 5.x an output object whose pooler_output is it)
+        emb = lambda o: o if torch.is_tensor(o) else o.pooler_output
+        img = emb(self.model.get_image_features(pixel_values=inp["pixel_values"]))
+        txt = emb(self.model.get_text_features(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"]))
         img = img / img.norm(p=2, dim=-1, keepdim=True)
         txt = txt / txt.norm(p=2, dim=-1, keepdim=True)
         self.score += (100 * (img * txt).sum(-1)).clamp(min=0).sum().item()

@@ -35,7 +35,7 @@ from .registry import models_registry
 from .schedulers import PNDMConfigStub
 from .unet import CACHE_FULL_AND_STORE, CACHE_OFF, CACHE_SKIP, HipUNet2DConditionModel
 from .vae import HipVaeDecoder, VaeConfig, load_vae_state_dict, make_synthetic_vae_state_dict
-from .weights import UNetConfig, load_unet_state_dict, make_synthetic_state_dict
+from .weights import UNetConfig, load_unet_config, load_unet_state_dict, make_synthetic_state_dict
 
 
 @dataclass
@@ -110,7 +110,7 @@ class StableDiffusionModel:
             has_clip = all(os.path.exists(os.path.join(path, *p)) for p in (("tokenizer", "vocab.json"),
                                                                             ("tokenizer", "merges.txt"),
                                                                             ("text_encoder", "model.safetensors")))
-            return cls(state_dict=load_unet_state_dict(path), source=f"local:{path}",
+            return cls(unet_config=load_unet_config(path), state_dict=load_unet_state_dict(path), source=f"local:{path}",
                        clip_dir=path if has_clip else None, **kwargs)
         seed = int(os.environ.get("SD_AMD_WEIGHTS_SEED", "1234"))
         return cls(weights_seed=seed, source=f"synthetic(seed={seed}) for {pretrained_model_name_or_path}", **kwargs)

@@ -37,6 +37,19 @@ def _c_config(cfg: UNetConfig, weight_dtype: str = "bf16", fp8_act_scales=(0.0, 
     return c
 
 
+def load_params(lib, handle, config: UNetConfig, state_dict: Dict[str, torch.Tensor]) -> None:
+    """Every parameter ``param_shapes(config)`` names, checked for presence and shape, into the handle
+    (``sd_unet_load_param`` copies; host-only, runs without a GPU).  Tensors of any float dtype are accepted --
+    diffusers checkpoints are fp16 on disk."""
+    for name, shape in param_shapes(config):
+        if name not in state_dict:
+            raise KeyError(f"state_dict lacks UNet parameter {name!r}")
+        t = state_dict[name].detach().to("cpu", torch.float32).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+        _lib.check(lib.sd_unet_load_param(handle, name.encode(), t.data_ptr(), t.numel()), f"sd_unet_load_param({name})")
+
+
 class HipUNet2DConditionModel:
     """SD-1.5 UNet running on libsdhip.  ``config`` mirrors the diffusers attributes the
     reference loop reads (``in_channels``, ``sample_size``, ``time_cond_proj_dim``)."""
@@ -57,14 +70,7 @@ class HipUNet2DConditionModel:
         self.weight_dtype = "fp8_e4m3" if _lib.DTYPES.get(weight_dtype) == _lib.DTYPE_FP8_E4M3 else "bf16"
         ccfg = _c_config(config, weight_dtype, fp8_act_scales)
         _lib.check(self._lib.sd_unet_create(C.byref(ccfg), C.byref(self._handle)), "sd_unet_create")
-        for name, shape in param_shapes(config):
-            if name not in state_dict:
-                raise KeyError(f"state_dict lacks UNet parameter {name!r}")
-            t = state_dict[name].detach().to("cpu", torch.float32).contiguous()
-            if tuple(t.shape) != tuple(shape):
-                raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
-            _lib.check(self._lib.sd_unet_load_param(self._handle, name.encode(), t.data_ptr(), t.numel()),
-                       f"sd_unet_load_param({name})")
+        load_params(self._lib, self._handle, config, state_dict)
         _lib.check(self._lib.sd_unet_finalize(self._handle), "sd_unet_finalize")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key = None

@@ -125,6 +125,45 @@ def make_synthetic_state_dict(cfg: UNetConfig, seed: int = 1234) -> Dict[str, to
     return sd
 
 
+def load_unet_config(model_dir: str) -> "UNetConfig | None":
+    """``<dir>/unet/config.json`` of a LOCAL diffusers checkpoint -> ``UNetConfig`` (None if the file is absent: the
+    SD-1.5 defaults then apply).  Only the keys this build implements are read; a checkpoint that needs anything else
+    (another block type, ``use_linear_projection``, per-level head counts that are not ``attention_head_dim`` heads
+    at every level, an activation other than silu) is refused here rather than mis-run."""
+    import json
+    for cand in (os.path.join(model_dir, "unet", "config.json"), os.path.join(model_dir, "config.json")):
+        if os.path.isfile(cand):
+            with open(cand) as f:
+                c = json.load(f)
+            break
+    else:
+        return None
+    down = list(c.get("down_block_types", ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]))
+    up = list(c.get("up_block_types", ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3))
+    known = {"CrossAttnDownBlock2D": True, "DownBlock2D": False}
+    if any(d not in known for d in down):
+        raise NotImplementedError(f"down_block_types {down}: CrossAttnDownBlock2D / DownBlock2D are built")
+    attn = tuple(known[d] for d in down)
+    if [u == "CrossAttnUpBlock2D" for u in up] != list(reversed(attn)):
+        raise NotImplementedError(f"up_block_types {up} do not mirror down_block_types {down}")
+    heads = c.get("attention_head_dim", 8)          # SD-1.5 quirk: this key holds the NUMBER of heads (SURVEY A.1)
+    if isinstance(heads, (list, tuple)):
+        if len(set(heads)) != 1:
+            raise NotImplementedError("per-level head counts are not built")
+        heads = heads[0]
+    for key, want in (("use_linear_projection", False), ("act_fn", "silu"), ("flip_sin_to_cos", True), ("freq_shift", 0),
+                      ("time_cond_proj_dim", None), ("class_embed_type", None), ("addition_embed_type", None),
+                      ("dual_cross_attention", False), ("only_cross_attention", False), ("upcast_attention", False)):
+        if c.get(key, want) != want:
+            raise NotImplementedError(f"unet config {key}={c[key]!r}: this build implements {want!r} (SD-1.5)")
+    return UNetConfig(sample_size=int(c.get("sample_size", 64)), in_channels=int(c.get("in_channels", 4)),
+                      out_channels=int(c.get("out_channels", 4)),
+                      block_out_channels=tuple(int(v) for v in c.get("block_out_channels", (320, 640, 1280, 1280))),
+                      layers_per_block=int(c.get("layers_per_block", 2)), attn_levels=attn,
+                      cross_attention_dim=int(c.get("cross_attention_dim", 768)), num_heads=int(heads),
+                      norm_num_groups=int(c.get("norm_num_groups", 32)), norm_eps=float(c.get("norm_eps", 1e-5)))
+
+
 def load_unet_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
     """Load a LOCAL diffusers UNet (``<dir>/unet/diffusion_pytorch_model.safetensors``).
     Never fetches: names that are not local directories raise."""

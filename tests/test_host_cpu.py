@@ -448,3 +448,161 @@ def test_geglu_polynomial_gelu_error_bound():
     x64 = x.astype(np.float64)
     ref = x64 * 0.5 * (1 + erf(x64 / np.sqrt(2)))
     assert (np.abs(got - ref) / np.maximum(np.abs(x64), 1e-3)).max() < 1.3e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# the path REAL weights take: from_pretrained(<local diffusers dir>) -> load_unet_config / load_unet_state_dict -> handle
+# ---------------------------------------------------------------------------------------------------
+def _write_tiny_diffusers_dir(root, cfg, sd, dtype=torch.float16):
+    import json
+    from safetensors.torch import save_file
+    os.makedirs(os.path.join(root, "unet"), exist_ok=True)
+    nl = len(cfg.block_out_channels)
+    json.dump({"_class_name": "UNet2DConditionModel", "sample_size": cfg.sample_size, "in_channels": 4, "out_channels": 4,
+               "block_out_channels": list(cfg.block_out_channels), "layers_per_block": cfg.layers_per_block,
+               "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in cfg.attn_levels],
+               "up_block_types": ["CrossAttnUpBlock2D" if a else "UpBlock2D" for a in reversed(cfg.attn_levels)],
+               "cross_attention_dim": cfg.cross_attention_dim, "attention_head_dim": cfg.num_heads, "norm_num_groups": 32,
+               "norm_eps": 1e-5, "act_fn": "silu", "use_linear_projection": False, "flip_sin_to_cos": True, "freq_shift": 0},
+              open(os.path.join(root, "unet", "config.json"), "w"))
+    save_file({k: v.to(dtype) for k, v in sd.items()}, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    assert nl == len(cfg.attn_levels)
+
+
+def test_from_pretrained_local_directory_reaches_the_library(tmp_path):
+    """``from_pretrained(<local dir>)`` (src/experiments/base_experiment.py:55-64): ``unet/config.json`` becomes the
+    UNetConfig, the fp16 safetensors become the state dict, and every parameter the library enumerates for that config is
+    accepted by ``sd_unet_load_param`` and packed by ``sd_unet_finalize`` (which then stops at the upload: no GPU here)."""
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
+    from sonicdiffusionbayeslab_amd.unet import _c_config, load_params
+    from sonicdiffusionbayeslab_amd.weights import make_synthetic_state_dict
+    cfg = UNetConfig(sample_size=8, block_out_channels=(320, 640), attn_levels=(True, False))
+    sd = make_synthetic_state_dict(cfg, seed=11)
+    _write_tiny_diffusers_dir(str(tmp_path), cfg, sd)
+    m = StableDiffusionModel.from_pretrained(str(tmp_path), timestamps=None, safety_checker=None,
+                                             requires_safety_checker=False, torch_dtype=torch.float16)
+    assert m.weights_source == f"local:{tmp_path}" and m._clip_dir is None
+    assert m.unet_config == cfg
+    got = m._state_dict
+    assert set(got) == {n for n, _ in param_shapes(cfg)}
+    # bf16-grid values survive the fp16 file exactly only where fp16 can hold them; everything is within fp16 rounding
+    for n, shape in param_shapes(cfg):
+        assert tuple(got[n].shape) == tuple(shape) and got[n].dtype == torch.float32
+        assert torch.allclose(got[n], sd[n], rtol=2 ** -10, atol=2 ** -24)
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.sd_unet_create(C.byref(_c_config(m.unet_config)), C.byref(h)))
+    load_params(lib, h, m.unet_config, got)
+    if not torch.cuda.is_available():
+        assert lib.sd_unet_finalize(h) == -2 and b"hipMalloc" in lib.sd_last_error()     # packed; no device to upload to
+        assert lib.sd_unet_debug_packed(h, b"down_blocks.0.attentions.0.ff_out.weight", None, 0) >= 0
+    lib.sd_unet_destroy(h)
+    # a missing / mis-shaped parameter and an unsupported architecture key are refused, not mis-run
+    bad = dict(got); bad.pop("conv_in.bias")
+    h2 = C.c_void_p()
+    _lib.check(lib.sd_unet_create(C.byref(_c_config(cfg)), C.byref(h2)))
+    with pytest.raises(KeyError):
+        load_params(lib, h2, cfg, bad)
+    bad["conv_in.bias"] = torch.zeros(7)
+    with pytest.raises(ValueError):
+        load_params(lib, h2, cfg, bad)
+    lib.sd_unet_destroy(h2)
+    import json
+    cj = os.path.join(str(tmp_path), "unet", "config.json")
+    c = json.load(open(cj)); c["use_linear_projection"] = True; json.dump(c, open(cj, "w"))
+    with pytest.raises(NotImplementedError):
+        StableDiffusionModel.from_pretrained(str(tmp_path))
+    # a hub NAME is never fetched: synthetic weights, and the report says so
+    m2 = StableDiffusionModel.from_pretrained("runwayml/stable-diffusion-v1-5")
+    assert m2.weights_source.startswith("synthetic(") and m2._state_dict is None
+
+
+def _write_tiny_clip_dir(root):
+    """A randomly initialised CLIP (text + vision towers, projection) with a synthetic byte-level BPE vocabulary, saved the
+    way a local ``openai/clip-vit-base-patch16`` directory looks to ``CLIPModel / CLIPProcessor.from_pretrained``."""
+    import json
+    tr = pytest.importorskip("transformers")
+    from tests.util import synthetic_clip_vocab
+    vocab, merges = synthetic_clip_vocab()
+    json.dump(vocab, open(os.path.join(root, "vocab.json"), "w"))
+    open(os.path.join(root, "merges.txt"), "w").write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    tok = tr.CLIPTokenizer(os.path.join(root, "vocab.json"), os.path.join(root, "merges.txt"), model_max_length=16)
+    ip = tr.CLIPImageProcessor(size={"shortest_edge": 32}, crop_size={"height": 32, "width": 32})
+    tr.CLIPProcessor(image_processor=ip, tokenizer=tok).save_pretrained(root)
+    eos = vocab["<|endoftext|>"]
+    cfg = tr.CLIPConfig(text_config=dict(vocab_size=len(vocab), hidden_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                         intermediate_size=64, max_position_embeddings=16,
+                                         bos_token_id=vocab["<|startoftext|>"], eos_token_id=eos, pad_token_id=eos),
+                        vision_config=dict(hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                                           image_size=32, patch_size=8), projection_dim=16)
+    torch.manual_seed(0)
+    tr.CLIPModel(cfg).eval().save_pretrained(root)
+
+
+def test_clip_score_metric_and_its_wiring_into_validate(tmp_path, capsys):
+    """``clip_score`` = mean over pairs of max(100 cos(E_img, E_txt), 0) (torchmetrics CLIPScore, SURVEY A.8;
+    calc_clip_score.py:13-37) on a tiny random CLIP, and the harness: ``quality_metrics.clip_score.model_name_or_path``
+    pointing at a local directory makes ``validate`` report it for decoded images (base_experiment.py:96-98,198-201)."""
+    import json
+    tr = pytest.importorskip("transformers")
+    from sonicdiffusionbayeslab_amd.config import _wrap
+    from sonicdiffusionbayeslab_amd.experiments.base_experiment import BaseMethod
+    from sonicdiffusionbayeslab_amd.registry import metrics_registry
+    root = str(tmp_path)
+    _write_tiny_clip_dir(root)
+    with pytest.raises(FileNotFoundError):
+        metrics_registry["clip_score"]("openai/clip-vit-base-patch16")         # a hub name is never fetched
+    metric = metrics_registry["clip_score"](root)
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.rand((5, 3, 48, 40), generator=g)
+    texts = ["A photo of the cat", "the hat", "", "photo of a thing", "x" * 100]
+    u8 = (imgs * 255).to(torch.uint8)
+    metric.update(u8[:3], texts[:3]); metric.update(u8[3:], texts[3:])
+    model, proc = tr.CLIPModel.from_pretrained(root).eval(), tr.CLIPProcessor.from_pretrained(root)
+    with torch.no_grad():
+        inp = proc(text=texts, images=[i for i in u8], return_tensors="pt", padding=True, truncation=True)
+        out = model(**inp)
+    want = (100 * torch.nn.functional.cosine_similarity(out.image_embeds, out.text_embeds)).clamp(min=0).mean()
+    assert abs(float(metric.compute()) - float(want)) < 1e-3
+
+    class _Stub:
+        weights_source, num_timesteps = "stub", 2
+
+        def __init__(self):
+            self.unet_config = UNetConfig(sample_size=8)
+            self.scheduler = type("S", (), {"config": {}})()
+
+        def to(self, device):
+            return self
+
+        def __call__(self, prompts, generator=None, output_type="pt", **kw):
+            n = len(prompts)
+            return type("O", (), {"images": torch.rand((n, 3, 64, 64), generator=generator)})(), 0.1, []
+
+    class M(BaseMethod):
+        def setup_model(self):
+            self.model = _Stub()
+
+        def setup_scheduler(self, **kw):
+            pass
+
+        def run_experiment(self):
+            self.sweep([2], lambda n: {"num_inference_steps": n}, lambda n: f"steps {n}")
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {"experiment_name": "stub", "experiment": {"method": "stub", "seed": 29},
+            "dataset": {"img_dataset": "", "prompts": os.path.join(repo, "data", "dataset", "img2annotations_test.json")},
+            "inference": {"batch_size": 3, "batch_count": 2}}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SD_DIST_FORCE_INIT"):
+        os.environ.pop(k, None)
+    m = M(_wrap(dict(base, quality_metrics={"clip_score": {"model_name_or_path": root}})))
+    m.device = "cpu"
+    m.run_experiment()
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["images"] == 6 and line["clip_score_model"] == root and 0.0 <= line["clip_score"] <= 100.0
+    assert m.metric_dict["clip_score"] == [line["clip_score"]]
+    m2 = M(_wrap(dict(base, quality_metrics={"clip_score": {"model_name_or_path": "openai/clip-vit-base-patch16"}})))
+    m2.device = "cpu"
+    m2.run_experiment()
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["clip_score"] is None and "not computable offline" in line["clip_score_model"]
