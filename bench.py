@@ -53,32 +53,93 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, args):
-    """Oracle timed on the host cores on a bounded sample of configs[0] (B=1, DDIM, CFG)."""
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(cfg, sd, args, gpu_traj=None):
+    """Oracle timed on the host cores on a bounded sample of configs[0] (B=1, DDIM, CFG): fp32 primary, and a shorter
+    fp16 leg (the reference loads torch_dtype=float16 on the CPU too, src/experiments/base_experiment.py:62).  The oracle's
+    free-running latents after its n steps also CHECK the GPU path's latents after the same n steps from the same
+    inputs (``gpu_traj``: latents after each of the first steps): returned as ``parity``."""
     from oracle.unet import UNetConfig as OC, unet_forward
     from oracle.schedulers import DDIMOracle
     import dataclasses
     ocfg = OC(**dataclasses.asdict(cfg))
+    lat0, ctx = parity_inputs(cfg)
+
+    def run(dtype, budget, max_steps):
+        w = sd if dtype == torch.float32 else {k: v.to(dtype) for k, v in sd.items()}
+        lat, c = lat0.to(dtype), ctx.to(dtype)
+        sch = DDIMOracle()
+        sch.set_timesteps(args.ddim_steps)
+        n_done, t0 = 0, time.time()
+        with torch.no_grad():
+            for t in sch.timesteps[:max_steps]:
+                e = unet_forward(w, ocfg, torch.cat([lat, lat]), t, c).float()
+                u, cnd = e.chunk(2)
+                lat = sch.step(u + 7.5 * (cnd - u), t, lat.float())[0].to(dtype)
+                n_done += 1
+                if time.time() - t0 > budget:
+                    break
+        return n_done, time.time() - t0, lat.float()
+
+    n_done, dt, lat32 = run(torch.float32, args.cpu_seconds, len(gpu_traj) if gpu_traj else args.ddim_steps)
+    per_step = dt / n_done
+    out = {"value": 1.0 / (per_step * args.ddim_steps), "unit": "images/s", "cores": torch.get_num_threads(),
+           "kind": "port", "cpu_model": cpu_model_string(), "dtype": "fp32",
+           "sample": f"{n_done} of {args.ddim_steps} DDIM steps (CFG pair UNet forward + step, batch 1, fp32 "
+                     f"PyTorch-CPU oracle) in {dt:.1f}s, extrapolated to {args.ddim_steps} steps"}
+    try:
+        n16, dt16, _ = run(torch.float16, max(args.cpu_seconds / 3.0, 5.0), 1)      # one step: half kernels on a CPU can be slow
+        out["fp16"] = {"value": 1.0 / (dt16 / n16 * args.ddim_steps), "unit": "images/s",
+                       "sample": f"{n16} of {args.ddim_steps} DDIM steps in {dt16:.1f}s with fp16 weights and activations "
+                                 "(what the reference's CPU path would run: torch_dtype=float16)"}
+    except Exception as e:                                    # an ATen CPU op without a half kernel: say so, do not fail the bench
+        out["fp16"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    parity = None
+    if gpu_traj and n_done <= len(gpu_traj):
+        got = gpu_traj[n_done - 1].float().cpu()
+        d = got - lat32
+        parity = {"against": "fp32 CPU oracle (oracle/: this build's restatement, PARITY UNPINNED -- DESIGN.md 2)",
+                  "what": f"free-running latents after the first {n_done} of {args.ddim_steps} DDIM steps, CFG 7.5, batch 1, "
+                          f"{cfg.sample_size}x{cfg.sample_size} latents, same seeded inputs and weights",
+                  "max_abs": d.abs().max().item(), "rel_l2": (d.norm() / lat32.norm()).item(),
+                  "cosine": (got.flatten() @ lat32.flatten() / (got.norm() * lat32.norm())).item()}
+    return out, parity
+
+
+def parity_inputs(cfg):
     g = torch.Generator().manual_seed(29)
     lat = torch.randn((1, 4, cfg.sample_size, cfg.sample_size), generator=g)
     ctx = torch.randn((2, cfg.context_len, cfg.cross_attention_dim), generator=g)
-    sch = DDIMOracle()
-    sch.set_timesteps(args.ddim_steps)
-    n_done, t0 = 0, time.time()
-    with torch.no_grad():
-        for t in sch.timesteps:
-            e = unet_forward(sd, ocfg, torch.cat([lat, lat]), t, ctx)
-            u, c = e.chunk(2)
-            lat = sch.step(u + 7.5 * (c - u), t, lat)[0]
-            n_done += 1
-            if time.time() - t0 > args.cpu_seconds:
-                break
-    dt = time.time() - t0
-    per_step = dt / n_done
-    return {"value": 1.0 / (per_step * args.ddim_steps), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{n_done} of {args.ddim_steps} DDIM steps (CFG pair UNet forward + step, batch 1, fp32 "
-                      f"PyTorch-CPU oracle) in {dt:.1f}s, extrapolated to {args.ddim_steps} steps"}
+    return lat, ctx
+
+
+def gpu_free_running(model, cfg, args, dev, n_steps=12):
+    """The GPU path on the cpu_baseline sample: latents after each of the first ``n_steps`` DDIM steps (CFG 7.5, batch 1)."""
+    from sonicdiffusionbayeslab_amd.registry import schedulers_registry
+    from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
+    lat, ctx = parity_inputs(cfg)
+    s = schedulers_registry["ddim_scheduler"].from_config(PNDMConfigStub().config)
+    s.set_timesteps(args.ddim_steps, device=dev)
+    model.unet.set_deepcache(-1)
+    model.unet.set_context(ctx.to(dev))
+    x, traj = lat.to(dev), []
+    for t in s._timesteps_list[:n_steps]:
+        eps = model.unet.forward_latents(x, 2, float(t))
+        x, _ = s.step_fused(eps, 7.5, x, t, cfg=True)
+        traj.append(x.clone())
+    torch.cuda.synchronize()
+    return traj
 
 
 def end_to_end(model, args, dev):
@@ -117,34 +178,67 @@ def end_to_end(model, args, dev):
     return best
 
 
-TRAFFIC_SOURCE = ("profiles/round2_conv_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                  "tools/run_traffic.sh; NOT measured in this run)")
-PMC_SOURCE = ("profiles/round2_pmc_forward.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of "
-              "tools/run_pmc_forward.sh; NOT measured in this run)")
+PROFILE_ROUND = "round3"
+TRAFFIC_FILE = f"profiles/{PROFILE_ROUND}_conv_traffic.json"
+PMC_FILE = f"profiles/{PROFILE_ROUND}_pmc_forward.json"
+TRAFFIC_SOURCE = (f"{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_traffic.sh over "
+                  "tools/forward_once.py at this bench shape; NOT measured in this run; nulled when the kernel sources "
+                  "have changed since that profile was taken)")
+PMC_SOURCE = (f"{PMC_FILE} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of tools/run_pmc_forward.sh; "
+              "NOT measured in this run; nulled when the kernel sources have changed since)")
+
+
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources a committed PMC profile belongs to (the GPU box has no .git): sha256 over
+    csrc/*.hip + csrc/*.h in name order, first 16 hex digits.  tools/pmc_*.py stamp it into the profile JSON and the
+    readers below refuse a profile whose stamp is not the current one (a stale counter is worse than none)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "sonicdiffusionbayeslab_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _profile(path):
+    """(json, None) of a committed profile if it carries the current kernel fingerprint, else (None, reason)."""
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, f"{path} absent"
+    have = d.get("kernel_sources_sha16")
+    if have != kernel_sources_sha16():
+        return None, f"{path} is stale (taken on kernel sources {have}, current {kernel_sources_sha16()})"
+    return d, None
 
 
 def conv_mfma_busy():
     """MFMA-busy fraction of the dominant kernel from the committed PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
-    shader cycles of the dispatch); None if the file is absent."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_forward.json")
+    shader cycles of the dispatch); (None, reason) if the profile is absent or stale."""
+    d, why = _profile(PMC_FILE)
+    if d is None:
+        return None, why
     try:
-        with open(p) as f:
-            return float(json.load(f)["conv_halo_kernel<0>"]["mfma_busy_frac"])
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+        return float(d["conv_halo_kernel<0>"]["mfma_busy_frac"]), None
+    except (KeyError, ValueError, TypeError):
+        return None, f"{PMC_FILE} has no conv_halo_kernel<0> row"
 
 
 def conv_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/run_traffic.sh ->
-    profiles/round2_conv_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the 50 conv launches of
-    one forward at this bench shape).  PMC counters cannot be read live inside this process, so the number is
-    the profile's; None if the file is absent."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_conv_traffic.json")
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes ((2*FETCH_SIZE + WRITE_SIZE)*1024
+    averaged over the kernel's launches of one forward at this bench shape, MI355X_MICROARCH.md's gfx950 correction).
+    PMC counters cannot be read live inside this process; (None, reason) if the profile is absent or stale."""
+    d, why = _profile(TRAFFIC_FILE)
+    if d is None:
+        return None, why
     try:
-        with open(p) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        return float(d["hbm_bytes_per_launch"]), None
+    except (KeyError, ValueError):
+        return None, f"{TRAFFIC_FILE} has no hbm_bytes_per_launch"
 
 
 def spawn_ranks(args) -> int:
@@ -314,9 +408,11 @@ def main():
                                       "conv_halo_kernel (3x3 conv, LDS-resident input halo; the stride-1 convs of a forward: 44 of its 50 conv launches "
                                       "-- the 3 stride-2 convs and the 3 sub-pixel upsamplers run on the implicit-GEMM kernel, kernel_breakdown.conv3x3_gemm)"),
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                           "frac": ach / peak, "traffic": None if fp8 else conv_traffic_bytes(),
-                           "traffic_source": None if fp8 else TRAFFIC_SOURCE,
-                           "mfma_busy": None if fp8 else conv_mfma_busy(), "mfma_busy_source": None if fp8 else PMC_SOURCE,
+                           "frac": ach / peak, "traffic": None if fp8 else conv_traffic_bytes()[0],
+                           "traffic_source": None if fp8 else (conv_traffic_bytes()[1] or TRAFFIC_SOURCE),
+                           "mfma_busy": None if fp8 else conv_mfma_busy()[0],
+                           "mfma_busy_source": None if fp8 else (conv_mfma_busy()[1] or PMC_SOURCE),
+                           "kernel_sources_sha16": kernel_sources_sha16(),
                            "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
                            "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
         tot = sum(v["ms"] for v in prof.values())
@@ -334,7 +430,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_e2e and args.sample_size == 64:
         res["config"]["end_to_end"] = end_to_end(model, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+        traj = gpu_free_running(model, cfg, args, dev) if args.dtype == "bf16" and args.scheduler == "ddim" else None
+        res["cpu_baseline"], parity = cpu_baseline(cfg, sd, args, traj)
+        res["config"]["parity"] = parity
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

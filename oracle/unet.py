@@ -180,7 +180,7 @@ def unet_forward(w: Dict[str, torch.Tensor], cfg: UNetConfig, sample: torch.Tens
     tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
     if tt.numel() == 1:
         tt = tt.expand(n)
-    temb = timestep_embedding(tt, cfg.block_out_channels[0])
+    temb = timestep_embedding(tt, cfg.block_out_channels[0]).to(sample.dtype)      # "cast to model dtype" (A.2 step 1)
     temb = F.linear(temb, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"])
     temb = F.silu(temb)
     temb = F.linear(temb, w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])

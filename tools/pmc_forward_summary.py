@@ -42,7 +42,11 @@ for name, a in agg.items():
     ds = [times[i] for i in half if i in times and re.sub(r"^void ", "", re.sub(r"\([^()]*\)$", "", disp[i]["name"]).replace("(anonymous namespace)::", "")) == name]
     if ds:
         res[name]["avg_us_profiled"] = sum(ds) / len(ds)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha16
+res["kernel_sources_sha16"] = kernel_sources_sha16()          # bench.py refuses this profile once the kernels change
 json.dump(res, open(out, "w"), indent=1)
+res.pop("kernel_sources_sha16")
 for name, v in sorted(res.items(), key=lambda kv: -(kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES") or 0) * kv[1]["launches"]):
     mb = v["mfma_busy_frac"]
     print(f"{name[:70]:70s} n={v['launches']:3d} us={v.get('avg_us_profiled', 0):8.1f} mfma_busy={mb if mb is None else round(mb, 3)} "

@@ -21,5 +21,9 @@ fetch, write = mean2(vals["FETCH_SIZE"]), mean2(vals["WRITE_SIZE"])
 res = {"kernel": pat, "launches": len(ids), "FETCH_SIZE_KiB_mean": fetch, "WRITE_SIZE_KiB_mean": write,
        "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
        "note": "2x correction on FETCH_SIZE for 16-B-per-lane reads on gfx950; separate --pmc pass over tools/forward_once.py"}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha16
+res["kernel_sources_sha16"] = kernel_sources_sha16()          # bench.py refuses this profile once the kernels change
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
