@@ -46,7 +46,8 @@ typedef struct sd_unet_config {
      *                       feed-forward GEMMs (v_mfma_f32_16x16x128_f8f6f4, fp32 accumulate, dequantised in the
      *                       epilogue).  Attention, the prompt cross-attention, to_out / proj_out / shortcut GEMMs,
      *                       the down/upsampler convs and conv_in / conv_out stay bf16.
-     * fp8_act_scale_*: activation scales x_fp8 = sat(x * scale) (0 = the defaults 8 and 2). */
+     * fp8_act_scale_*: DEFAULT activation scales x_fp8 = sat(x * scale) (0 = 8 and 2) of tensors that
+     * sd_unet_calibrate_fp8 / sd_unet_set_fp8_scale have not given a scale of their own. */
     int weight_dtype;
     float fp8_act_scale_norm;    /* GroupNorm(+SiLU) / LayerNorm outputs */
     float fp8_act_scale_ff;      /* GEGLU outputs (input of ff.net.2) */
@@ -74,6 +75,24 @@ int sd_unet_finalize(sd_unet* u);
  * copies `nbytes` of the packed item `key` (a diffusers parameter name; fp8 items: name + ".fp8" / ".scale") out of
  * it.  Returns the item's byte offset, < 0 on error (unknown key, blob already released after a successful upload). */
 long long sd_unet_debug_packed(const sd_unet* u, const char* key, void* host_out, long long nbytes);
+
+/* ---- fp8 activation scales (SD_DTYPE_FP8_E4M3 handles; no reference counterpart: the reference runs fp16,
+ * configs/consistency_model_config.yaml:1-34).  Every e4m3 ACTIVATION tensor of the plan is named after the module that
+ * writes it -- "<resnet>.norm1|norm2", "<Transformer2DModel>.norm", "<block>.norm1|norm3", "<block>.ff.net.0" (the GEGLU
+ * product) -- and carries one per-tensor scale, x_fp8 = sat(x * scale); e4m3 is a floating-point format, so the scale only
+ * positions the +-448 .. 2^-9 range over the tensor's values.
+ *   sd_unet_calibrate_fp8: ONE forward on the caller's inputs (sd_unet_set_context first, as for sd_unet_forward); every
+ *     producer of an e4m3 tensor is first run with a probe scale under which nothing saturates, the tensor's largest
+ *     |value| is read back, and its scale becomes the largest power of two <= 448 / (margin * amax) -- amax is the
+ *     maximum over all calibration calls so far (call it for a few timesteps).  Synchronises the stream ~125 times; all
+ *     plans are rebuilt afterwards (same workspace layout).  margin in [1, 64].
+ *   sd_unet_fp8_scale_count / _info: the named tensors known so far (names appear when a plan is built), their scale and
+ *     observed amax (0 = never calibrated);  sd_unet_set_fp8_scale: restore a saved calibration. */
+int sd_unet_calibrate_fp8(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch, float timestep,
+                          float margin, void* workspace, long long workspace_bytes);
+int sd_unet_fp8_scale_count(const sd_unet* u);
+int sd_unet_fp8_scale_info(const sd_unet* u, int index, char* name, int name_cap, float* scale, float* amax);
+int sd_unet_set_fp8_scale(sd_unet* u, const char* name, float scale);
 
 /* Workspace the caller must provide for a given UNet batch (2*B with CFG).  `cache_branch_id`
  * < 0 disables the DeepCache plan; >= 0 reserves the cached tensors of that branch

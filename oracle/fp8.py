@@ -10,7 +10,8 @@ Scheme (identical in csrc/unet.hip):
   * weights of the resnet 3x3 convs, proj_in, attn1 to_q/to_k/to_v, ff.net.0.proj and ff.net.2: OCP e4m3fn, one
     fp32 scale per OUTPUT channel (row): scale = amax / 448, w_q = rne(w / scale), saturating;
   * the activations entering those contractions -- GroupNorm(+SiLU) and LayerNorm outputs (scale ``s_norm``) and the
-    GEGLU product (scale ``s_ff``) -- e4m3 of ``clamp(x * s, +-448)`` with a static per-tensor scale;
+    GEGLU product (scale ``s_ff``) -- e4m3 of ``clamp(x * s, +-448)`` with a static per-tensor scale (the defaults, or
+    the per-tensor scales of the product's calibration, ``scales``);
   * everything else (attention, cross-attention, to_out, proj_out, shortcuts, down/upsampler convs, conv_in/out)
     is not quantised.
 """
@@ -42,8 +43,12 @@ QUANTISED_SUFFIXES = (".conv1.weight", ".conv2.weight", ".proj_in.weight", ".att
 
 
 class Fp8Emulation:
-    def __init__(self, weights: Dict[str, torch.Tensor], s_norm: float = 8.0, s_ff: float = 2.0):
+    def __init__(self, weights: Dict[str, torch.Tensor], s_norm: float = 8.0, s_ff: float = 2.0, scales=None):
+        """``scales``: {tensor name: scale} as ``HipUNet2DConditionModel.fp8_scales()`` returns them (the product's
+        calibrated per-tensor scales; names = the module that writes the tensor: "<resnet>.norm1", "<attn>.norm",
+        "<block>.norm1|norm3", "<block>.ff.net.0"); tensors without an entry use the defaults ``s_norm`` / ``s_ff``."""
         self.s_norm, self.s_ff = float(s_norm), float(s_ff)
+        self.scales = dict(scales or {})
         self.wq: Dict[str, torch.Tensor] = {}
         for name, w in weights.items():
             if name.endswith(QUANTISED_SUFFIXES) and ("resnets." in name or "attentions." in name):
@@ -53,8 +58,10 @@ class Fp8Emulation:
     def w(self, weights, name):
         return self.wq.get(name, weights[name])
 
-    def act_norm(self, x):
-        return e4m3_round(x * self.s_norm) / self.s_norm
+    def act_norm(self, x, name=None):
+        s = float(self.scales.get(name, self.s_norm))
+        return e4m3_round(x * s) / s
 
-    def act_ff(self, x):
-        return e4m3_round(x * self.s_ff) / self.s_ff
+    def act_ff(self, x, name=None):
+        s = float(self.scales.get(name, self.s_ff))
+        return e4m3_round(x * s) / s

@@ -19,6 +19,7 @@ wrapped sub-module goes through ``_cached`` which returns the stored output on s
 from __future__ import annotations
 
 import math
+import time
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -100,21 +101,35 @@ def timestep_embedding(t: torch.Tensor, dim: int = 320) -> torch.Tensor:
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 
 
+# Optional wall-clock bound for callers that TIME the oracle (bench.py's cpu_baseline leg): checked between blocks, so an
+# unexpectedly slow dtype path (fp16 on a CPU without vectorised half kernels) stops after at most one block too many.
+DEADLINE = None
+BLOCKS_DONE = 0
+
+
+def _tick():
+    global BLOCKS_DONE
+    BLOCKS_DONE += 1
+    if DEADLINE is not None and time.time() > DEADLINE:
+        raise TimeoutError(f"oracle deadline reached after {BLOCKS_DONE} blocks")
+
+
 def resnet_block(w, p: str, x: torch.Tensor, temb: torch.Tensor, cfg: UNetConfig, fq=None) -> torch.Tensor:
     """ResnetBlock2D (A.3).  ``fq`` (oracle/fp8.py::Fp8Emulation) applies the build's fp8 rounding points."""
+    _tick()
     g = cfg.norm_num_groups
     W = (lambda n: fq.w(w, n)) if fq is not None else (lambda n: w[n])
     h = F.group_norm(x, g, w[p + "norm1.weight"], w[p + "norm1.bias"], cfg.norm_eps)
     h = F.silu(h)
     if fq is not None:
-        h = fq.act_norm(h)
+        h = fq.act_norm(h, p + "norm1")
     h = F.conv2d(h, W(p + "conv1.weight"), w[p + "conv1.bias"], padding=1)
     tp = F.linear(F.silu(temb), w[p + "time_emb_proj.weight"], w[p + "time_emb_proj.bias"])
     h = h + tp[:, :, None, None]
     h = F.group_norm(h, g, w[p + "norm2.weight"], w[p + "norm2.bias"], cfg.norm_eps)
     h = F.silu(h)
     if fq is not None:
-        h = fq.act_norm(h)
+        h = fq.act_norm(h, p + "norm2")
     h = F.conv2d(h, W(p + "conv2.weight"), w[p + "conv2.bias"], padding=1)
     if (p + "conv_shortcut.weight") in w:
         x = F.conv2d(x, w[p + "conv_shortcut.weight"], w[p + "conv_shortcut.bias"])
@@ -139,24 +154,25 @@ def _attention(w, p: str, x: torch.Tensor, ctx: torch.Tensor, heads: int, fq=Non
 
 def transformer_block(w, p: str, x: torch.Tensor, ctx: torch.Tensor, cfg: UNetConfig, fq=None) -> torch.Tensor:
     """Transformer2DModel with one BasicTransformerBlock (A.4), use_linear_projection=False."""
+    _tick()
     b, c, hh, ww = x.shape
     res = x
     W = (lambda n: fq.w(w, n)) if fq is not None else (lambda n: w[n])
-    A = fq.act_norm if fq is not None else (lambda v: v)
+    A = fq.act_norm if fq is not None else (lambda v, name=None: v)
     h = F.group_norm(x, cfg.norm_num_groups, w[p + "norm.weight"], w[p + "norm.bias"], 1e-6)
-    h = F.conv2d(A(h), W(p + "proj_in.weight"), w[p + "proj_in.bias"])
+    h = F.conv2d(A(h, p + "norm"), W(p + "proj_in.weight"), w[p + "proj_in.bias"])
     h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
     t = p + "transformer_blocks.0."
-    n1 = A(F.layer_norm(h, (c,), w[t + "norm1.weight"], w[t + "norm1.bias"], 1e-5))
+    n1 = A(F.layer_norm(h, (c,), w[t + "norm1.weight"], w[t + "norm1.bias"], 1e-5), t + "norm1")
     h = h + _attention(w, t + "attn1.", n1, n1, cfg.num_heads, fq)
     n2 = F.layer_norm(h, (c,), w[t + "norm2.weight"], w[t + "norm2.bias"], 1e-5)
     h = h + _attention(w, t + "attn2.", n2, ctx, cfg.num_heads)          # the prompt cross-attention stays bf16
-    n3 = A(F.layer_norm(h, (c,), w[t + "norm3.weight"], w[t + "norm3.bias"], 1e-5))
+    n3 = A(F.layer_norm(h, (c,), w[t + "norm3.weight"], w[t + "norm3.bias"], 1e-5), t + "norm3")
     proj = F.linear(n3, W(t + "ff.net.0.proj.weight"), w[t + "ff.net.0.proj.bias"])
     a, gate = proj.chunk(2, dim=-1)
     hid = a * F.gelu(gate)
     if fq is not None:
-        hid = fq.act_ff(hid)
+        hid = fq.act_ff(hid, t + "ff.net.0")
     ff = F.linear(hid, W(t + "ff.net.2.weight"), w[t + "ff.net.2.bias"])
     h = h + ff
     h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)

@@ -60,6 +60,10 @@ _SIGS = {
     "sd_unet_load_param": (_i, [_vp, C.c_char_p, _vp, _ll]),
     "sd_unet_finalize": (_i, [_vp]),
     "sd_unet_debug_packed": (_ll, [_vp, C.c_char_p, _vp, _ll]),
+    "sd_unet_calibrate_fp8": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _ll]),
+    "sd_unet_fp8_scale_count": (_i, [_vp]),
+    "sd_unet_fp8_scale_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_f), C.POINTER(_f)]),
+    "sd_unet_set_fp8_scale": (_i, [_vp, C.c_char_p, _f]),
     "sd_unet_workspace_bytes": (_ll, [_vp, _i, _i]),
     "sd_unet_set_context": (_i, [_vp, _vp, _vp, _i, _i, _vp, _ll]),
     "sd_unet_forward": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _ll, _i, _i]),

@@ -110,6 +110,8 @@ int sd_launch_layernorm(const bf16_t* x, const float* gamma, const float* beta, 
 int sd_launch_layernorm_fp8(const bf16_t* x, const float* gamma, const float* beta, void* y, int rows, int C, int Cpad,
                             float eps, float oscale, hipStream_t stream);
 // bf16 [rows, C] -> e4m3 [rows, Cpad] of sat(x * scale), pad zero (tests; operands whose producer has no fp8 epilogue)
+// largest e4m3 magnitude code (byte & 0x7f) of `nbytes` e4m3 bytes -> atomicMax into *out (the caller zeroes it)
+int sd_launch_amax_e4m3(const void* y, long nbytes, unsigned* out, hipStream_t stream);
 int sd_launch_quantize_fp8(const bf16_t* x, void* y, long rows, int C, int Cpad, float scale, hipStream_t stream);
 
 struct AttnArgs {

@@ -9,6 +9,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace {
 
 struct GnGeom {
@@ -432,6 +434,23 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* __restr
 }
 
 // one wave per row; the row lives in registers (cols <= 4096)
+// largest e4m3 magnitude CODE (byte & 0x7f: monotonic in |value| on the OCP e4m3fn grid, 0x7f = NaN) of a tensor, by
+// atomicMax into *out (zeroed by the caller) -- the measurement behind sd_unet_calibrate_fp8
+__global__ __launch_bounds__(256) void amax_e4m3_kernel(const u32x4* __restrict__ y, long n16, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const u32x4 v = y[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned w = v[k] & 0x7f7f7f7fu;
+            m = max(m, max(max(w & 0xff, (w >> 8) & 0xff), max((w >> 16) & 0xff, w >> 24)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ s, long rows, int cols, float scale) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -582,6 +601,15 @@ int sd_launch_quantize_fp8(const bf16_t* x, void* y, long rows, int C, int Cpad,
     const long n = rows * (Cpad >> 3);
     hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, (char*)y, rows, C,
                        Cpad, scale);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sd_launch_amax_e4m3(const void* y, long nbytes, unsigned* out, hipStream_t stream) {
+    SD_REQUIRE(y && out && nbytes > 0 && nbytes % 16 == 0 && ((uintptr_t)y & 15) == 0, "amax_e4m3: %ld bytes, 16-byte granules", nbytes);
+    const long n16 = nbytes / 16;
+    const unsigned grid = (unsigned)std::min<long>((n16 + 255) / 256, 2048);
+    hipLaunchKernelGGL(amax_e4m3_kernel, dim3(grid), dim3(256), 0, stream, (const u32x4*)y, n16, out);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -114,6 +114,7 @@ struct Op {
     // the per-output-channel weight scales, xs = activation scale of its input; out_fp8: the op WRITES e4m3
     // (rows of Cpad bytes) with scale os.  Kalg: unpadded contraction length (algorithmic FLOPs).
     int dt = 0, out_fp8 = 0, Cpad = 0, Kalg = 0;
+    int sname = -1;                   // fp8 producer: index into sd_unet::act_names of the tensor it writes (its scale = os)
     // GroupNorm statistics from the producer's epilogue: `stats` = tensor this op writes ([M/64][N][2] fp32),
     // s1 / s2 = the statistics tensors of a GroupNorm's sources (it then skips its statistics pass)
     int stats = -1, s1 = -1, s2 = -1;
@@ -200,7 +201,20 @@ struct sd_unet {
     bool finalized = false;
     bool debug_taps = false;
     bool fp8 = false;                  // cfg.weight_dtype == SD_DTYPE_FP8_E4M3
-    float s_norm = 8.f, s_ff = 2.f;    // fp8 activation scales (GroupNorm / LayerNorm outputs, GEGLU outputs)
+    float s_norm = 8.f, s_ff = 2.f;    // fp8 activation scales (GroupNorm / LayerNorm outputs, GEGLU outputs): the DEFAULTS
+    // per-tensor activation scales (sd_unet_calibrate_fp8 / sd_unet_set_fp8_scale): every e4m3 activation tensor is named
+    // after the module that writes it ("<resnet>.norm1", "<attn>.norm", "<block>.norm1|3", "<block>.ff.net.0"); a tensor
+    // without an entry uses the default of its kind.  act_amax: largest |value| calibration has seen (0 = never calibrated).
+    std::vector<std::string> act_names;
+    std::unordered_map<std::string, int> act_index;
+    std::vector<float> act_scale, act_amax;
+    int act_id(const std::string& name, float dflt) {
+        auto it = act_index.find(name);
+        if (it != act_index.end()) return it->second;
+        act_index[name] = (int)act_names.size();
+        act_names.push_back(name); act_scale.push_back(dflt); act_amax.push_back(0.f);
+        return (int)act_names.size() - 1;
+    }
     std::map<std::tuple<int, int, int>, Plan> plans;     // (UNet batch, DeepCache branch, prefix replication)
     int last_rep = 1;                                    // variant of the last forward (sd_unet_debug_tensor)
     std::unordered_map<std::string, long> tproj_off;  // resnet prefix -> float index into tproj vector
@@ -871,6 +885,16 @@ struct Builder {
     int UB;
     std::vector<Wrap> wrapstack;
     std::map<int, int> stats_of;      // activation tensor -> statistics tensor written by its producer
+    std::map<int, float> tscale;      // e4m3 activation tensor -> the scale its producer wrote it with
+    static std::string stem(const std::string& key) {      // "....norm1.weight" -> "....norm1"
+        const size_t n = key.rfind(".weight");
+        return n == std::string::npos ? key : key.substr(0, n);
+    }
+    float xscale(int t) const {
+        auto it = tscale.find(t);
+        if (it == tscale.end()) { fprintf(stderr, "libsdhip: fp8 consumer of a tensor without a scale\n"); abort(); }
+        return it->second;
+    }
     // SD_GN_PRODUCER_STATS=0: every GroupNorm runs its own statistics pass (round-1 behaviour)
     bool producer_stats = !(getenv("SD_GN_PRODUCER_STATS") && atoi(getenv("SD_GN_PRODUCER_STATS")) == 0);
     void want_stats(Op& o, int M, int N) {      // called for producers whose output feeds a GroupNorm
@@ -950,8 +974,10 @@ struct Builder {
             o.s1 = stats_of[x1];
             o.s2 = x2 >= 0 ? stats_of[x2] : -1;
         }
-        if (fq) { o.out_fp8 = 1; o.Cpad = pad128(c1 + c2); o.os = u->s_norm; o.out = tensor((size_t)UB * hw * o.Cpad); }
-        else o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
+        if (fq) {
+            o.out_fp8 = 1; o.Cpad = pad128(c1 + c2); o.sname = u->act_id(stem(g), u->s_norm); o.os = u->act_scale[o.sname];
+            o.out = tensor((size_t)UB * hw * o.Cpad); tscale[o.out] = o.os;
+        } else o.out = tensor((size_t)UB * hw * (c1 + c2) * 2);
         push(o);
         return o.out;
     }
@@ -964,7 +990,7 @@ struct Builder {
         o.Hout = o.Wout = (hv + 2 - 3) / stride + 1;
         o.M = UB * o.Hout * o.Wout; o.K = 9 * cin; o.Kalg = o.K;
         o.b = W(b); o.b2t = b2t; o.b2idx = b2idx; o.r = r;
-        if (fq) { o.dt = 1; o.Cin = pad128(cin); o.K = 9 * o.Cin; o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = u->s_norm; }
+        if (fq) { o.dt = 1; o.Cin = pad128(cin); o.K = 9 * o.Cin; o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = xscale(x); }
         else o.w = W(w);
         // upsampler: nearest-2x + 3x3 as four 2x2 convs on the low-res input, 4/9 of the multiply-adds (SD_CONV_SUBPIXEL=0: off)
         static const bool subpix_off = getenv("SD_CONV_SUBPIXEL") && atoi(getenv("SD_CONV_SUBPIXEL")) == 0;
@@ -984,24 +1010,29 @@ struct Builder {
         push(o);
         return o.out;
     }
-    // fq = activation scale of an e4m3 x1 (0 = bf16 operands); oq = scale of an e4m3 OUTPUT (GEGLU epilogue only)
+    // fq: x1 is an e4m3 tensor (its scale comes from its producer); oname: name of the e4m3 tensor this GEMM WRITES (GEGLU
+    // epilogue only; empty = bf16 output)
     int gemm(int x1, int k1, int x2, int k2, int M, int N, const std::string& w, const std::string& b, int r, int epi,
-             float fq = 0.f, float oq = 0.f) {
+             bool fq = false, const std::string& oname = "") {
         Op o; o.kind = OP_GEMM; o.x1 = x1; o.x2 = x2; o.K1 = k1; o.K = k1 + k2; o.Kalg = o.K; o.M = M; o.N = N; o.epi = epi;
         o.b = b.empty() ? NOFF : W(b); o.r = r;
-        if (fq > 0.f) { o.dt = 1; o.K = o.K1 = pad128(k1); o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = fq; }
+        if (fq) { o.dt = 1; o.K = o.K1 = pad128(k1); o.w = W(w + ".fp8"); o.wsc = W(w + ".scale"); o.xs = xscale(x1); }
         else o.w = W(w);
         o.splitk = epi ? 1 : sd_gemm_splitk(M, N, o.dt ? o.K / 2 : o.K, o.dt ? 128 : 0);     // the heuristic counts 128-byte K tiles
         if (o.splitk > 1) o.aux = tensor((size_t)o.splitk * M * N * 4);
-        if (oq > 0.f) { o.out_fp8 = 1; o.os = oq; o.Cpad = pad128(N / 2); o.out = tensor((size_t)M * o.Cpad); }
-        else o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
+        if (!oname.empty()) {
+            o.out_fp8 = 1; o.sname = u->act_id(oname, u->s_ff); o.os = u->act_scale[o.sname]; o.Cpad = pad128(N / 2);
+            o.out = tensor((size_t)M * o.Cpad); tscale[o.out] = o.os;
+        } else o.out = tensor((size_t)M * (epi ? N / 2 : N) * 2);
         push(o);
         return o.out;
     }
     int ln(int x, int M, int C, const std::string& g, const std::string& b, bool fq = false) {
         Op o; o.kind = OP_LN; o.x1 = x; o.M = M; o.N = C; o.g = W(g); o.be = W(b); o.eps = 1e-5f;
-        if (fq) { o.out_fp8 = 1; o.Cpad = pad128(C); o.os = u->s_norm; o.out = tensor((size_t)M * o.Cpad); }
-        else o.out = tensor((size_t)M * C * 2);
+        if (fq) {
+            o.out_fp8 = 1; o.Cpad = pad128(C); o.sname = u->act_id(stem(g), u->s_norm); o.os = u->act_scale[o.sname];
+            o.out = tensor((size_t)M * o.Cpad); tscale[o.out] = o.os;
+        } else o.out = tensor((size_t)M * C * 2);
         push(o);
         return o.out;
     }
@@ -1030,15 +1061,14 @@ struct Builder {
         int M = UB * hw;
         const std::string t = p + "transformer_blocks.0.";
         const bool fq = u->fp8;
-        const float sn = fq ? u->s_norm : 0.f, sf = fq ? u->s_ff : 0.f;
         int g = gn(x, C, -1, 0, hw, p + "norm.weight", p + "norm.bias", 1e-6f, 0, fq);
-        int h0 = gemm(g, C, -1, 0, M, C, p + "proj_in.weight", p + "proj_in.bias", -1, 0, sn);
+        int h0 = gemm(g, C, -1, 0, M, C, p + "proj_in.weight", p + "proj_in.bias", -1, 0, fq);
         int qkv, rs = -1, np = 0;
         if (!fq && (np = want_rowstats(pl.ops.back(), M, C, rs)) > 0) {       // norm1 folded into the projection
             qkv = gemm_ln(h0, rs, np, M, 3 * C, C, t + "attn1.qkv.weight", 0);
         } else {
             int n1 = ln(h0, M, C, t + "norm1.weight", t + "norm1.bias", fq);
-            qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0, sn);
+            qkv = gemm(n1, C, -1, 0, M, 3 * C, t + "attn1.qkv.weight", "", -1, 0, fq);
         }
         // 64x64 level (head dim 40): the projection stores K and V head-major, [which][sample][head][token][40] behind the
         // token-major Q block, so that the self-attention's LDS-DMA pieces are contiguous (SD_ATTN_HEADMAJOR=0: off)
@@ -1106,7 +1136,7 @@ struct Builder {
             ff = gemm_ln(h2, rs, np, M, 8 * C, C, t + "ff.geglu.weight", 1);
         } else {
             int n3 = ln(h2, M, C, t + "norm3.weight", t + "norm3.bias", fq);
-            ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, sn, sf);
+            ff = gemm(n3, C, -1, 0, M, 8 * C, t + "ff.geglu.weight", t + "ff.geglu.bias", -1, 1, fq, fq ? t + "ff.net.0" : std::string());
         }
         // ff.net.2 + residual + proj_out + residual as ONE GEMM over [ff | h2] (Packer::ff_out_merge; SD_FF_MERGE=0: two)
         static const bool merge_off = getenv("SD_FF_MERGE") && atoi(getenv("SD_FF_MERGE")) == 0;
@@ -1114,7 +1144,7 @@ struct Builder {
         if (!fq && !merge_off) {
             out = gemm(ff, 4 * C, h2, C, M, C, p + "ff_out.weight", p + "ff_out.bias", x, 0);
         } else {
-            int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, sf);
+            int h3 = gemm(ff, 4 * C, -1, 0, M, C, t + "ff.net.2.weight", t + "ff.net.2.bias", h2, 0, fq);
             out = gemm(h3, C, -1, 0, M, C, p + "proj_out.weight", p + "proj_out.bias", x, 0);
         }
         // the block's output feeds the next resnet's GroupNorm (not at the small levels: their GroupNorms are single-launch or
@@ -1809,6 +1839,106 @@ extern "C" int sd_unet_forward(sd_unet* u, void* stream, const float* latents, i
         if ((rc = run_op(u, *pl, pl->ops[i], (char*)workspace, latents, latent_batch, eps_out, timestep, (hipStream_t)stream)))
             return rc;
     }
+    return 0;
+}
+
+// ---- fp8 activation-scale calibration (SD_DTYPE_FP8_E4M3 handles) -------------------------------------------------------
+// e4m3 is a floating-point format: a per-tensor scale buys no precision, it only positions the representable range
+// (+-448 down to 2^-9) over the tensor's values.  The static defaults (8 for norm outputs, 2 for the GEGLU product) clip
+// at |x| > 56 / 224; real checkpoints have layers beyond that.  Calibration runs ONE forward of the plan on the caller's
+// inputs op by op; every op that writes an e4m3 activation tensor is run twice: first with a probe scale under which
+// nothing can saturate, its largest |value| is read back from the e4m3 codes (a small reduction kernel + one host sync per
+// tensor: ~125 per forward, calibration only), then with its final scale  448 / (margin * amax)  so that the ops
+// downstream see correctly quantised inputs.  amax accumulates (max) over calls: calibrate on several timesteps / prompts,
+// then every plan is rebuilt with the new scales.
+static float e4m3_code_value(unsigned c) {
+    c &= 0x7f;
+    if (c == 0x7f) return 448.f;                       // NaN code: only a saturated probe could produce it
+    const int e = (int)(c >> 3), m = (int)(c & 7);
+    return e == 0 ? m * (1.f / 512.f) : (1.f + m / 8.f) * ldexpf(1.f, e - 7);
+}
+
+extern "C" int sd_unet_calibrate_fp8(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                                     float timestep, float margin, void* workspace, long long workspace_bytes) {
+    SD_REQUIRE(u && u->kind == 0 && u->fp8, "calibrate_fp8: not an fp8 UNet handle");
+    SD_REQUIRE(latents && workspace && latent_batch > 0 && unet_batch % latent_batch == 0, "calibrate_fp8: bad arguments");
+    SD_REQUIRE(margin >= 1.f && margin <= 64.f, "calibrate_fp8: margin %g (1 .. 64: headroom over the observed amax)", margin);
+    Plan* plp;
+    const int rep = plan_rep(u, latent_batch, unet_batch);
+    int rc = get_plan(u, unet_batch, -1, &plp, rep);
+    if (rc) return rc;
+    SD_REQUIRE((long long)plp->total_bytes <= workspace_bytes, "calibrate_fp8: workspace too small (%lld < %zu)", workspace_bytes,
+               plp->total_bytes);
+    SD_REQUIRE(((uintptr_t)workspace & 255) == 0, "calibrate_fp8: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* dmax = (unsigned*)op_scratch(256);
+    SD_REQUIRE(dmax, "calibrate_fp8: cannot allocate scratch");
+    std::vector<float> eps((size_t)unet_batch * u->cfg.out_channels * u->cfg.sample_size * u->cfg.sample_size);
+    float* deps = nullptr;
+    SD_CHECK_HIP(hipMalloc((void**)&deps, eps.size() * 4));
+    std::map<int, float> cur;                          // e4m3 tensor -> scale it was written with in THIS pass
+    const Plan& pl = *plp;
+    auto measure = [&](const Op& o, float probe, float* amax) -> int {
+        Op t = o; t.os = probe;
+        int r = run_op(u, pl, t, (char*)workspace, latents, latent_batch, deps, timestep, st);
+        if (r) return r;
+        SD_CHECK_HIP(hipMemsetAsync(dmax, 0, 4, st));
+        const Tn& tn = pl.tensors[o.out];
+        const long rows = o.kind == OP_GN ? (long)o.B * o.HW : (long)o.M;
+        if ((r = sd_launch_amax_e4m3((char*)workspace + tn.off, rows * o.Cpad, dmax, st))) return r;
+        unsigned code = 0;
+        SD_CHECK_HIP(hipMemcpyAsync(&code, dmax, 4, hipMemcpyDeviceToHost, st));
+        SD_CHECK_HIP(hipStreamSynchronize(st));
+        *amax = code >= 0x7e ? -1.f : e4m3_code_value(code) / probe;       // -1: the probe itself saturated
+        return 0;
+    };
+    for (size_t i = 0; i < pl.ops.size() && !rc; ++i) {
+        Op o = pl.ops[i];
+        if (o.dt) {                                    // consumer of an e4m3 tensor: the scale it was just written with
+            auto it = cur.find(o.x1);
+            if (it != cur.end()) o.xs = it->second;
+        }
+        if (o.out_fp8 && o.sname >= 0) {
+            float amax = 0.f;
+            rc = measure(o, 448.f / 4096.f, &amax);                        // |x| up to 4096, resolved down to ~0.15
+            if (!rc && amax < 0.f) rc = measure(o, 448.f / 1048576.f, &amax);
+            if (rc) break;
+            if (amax < 0.f) amax = 1048576.f;
+            float& seen = u->act_amax[o.sname];
+            seen = std::max(seen, amax);
+            // a power-of-two scale: the e4m3 grid is then an exact sub-grid of bf16 / fp32 values (reproducible emulation)
+            const float want = 448.f / (margin * std::max(seen, 1e-6f));
+            const float sc = ldexpf(1.f, (int)floorf(log2f(want)));
+            u->act_scale[o.sname] = std::min(std::max(sc, ldexpf(1.f, -20)), ldexpf(1.f, 20));
+            o.os = u->act_scale[o.sname];
+            cur[o.out] = o.os;
+        }
+        rc = run_op(u, pl, o, (char*)workspace, latents, latent_batch, deps, timestep, st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(deps);
+    if (rc) return rc;
+    u->plans.clear();                                  // every plan variant is rebuilt with the calibrated scales
+    return 0;
+}
+
+extern "C" int sd_unet_fp8_scale_count(const sd_unet* u) { return u ? (int)u->act_names.size() : -1; }
+
+extern "C" int sd_unet_fp8_scale_info(const sd_unet* u, int index, char* name, int name_cap, float* scale, float* amax) {
+    SD_REQUIRE(u && index >= 0 && index < (int)u->act_names.size(), "fp8_scale_info: bad index %d", index);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", u->act_names[index].c_str());
+    if (scale) *scale = u->act_scale[index];
+    if (amax) *amax = u->act_amax[index];
+    return 0;
+}
+
+extern "C" int sd_unet_set_fp8_scale(sd_unet* u, const char* name, float scale) {
+    SD_REQUIRE(u && u->kind == 0 && u->fp8 && name, "set_fp8_scale: not an fp8 UNet handle");
+    SD_REQUIRE(scale > 0.f && scale == scale, "set_fp8_scale: scale %g", scale);
+    auto it = u->act_index.find(name);
+    SD_REQUIRE(it != u->act_index.end(), "set_fp8_scale: no e4m3 activation tensor '%s' (build a plan first: sd_unet_workspace_bytes)", name);
+    u->act_scale[it->second] = scale;
+    u->plans.clear();
     return 0;
 }
 

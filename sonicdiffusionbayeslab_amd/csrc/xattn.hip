@@ -40,6 +40,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TOK = 128;                    // tokens per workgroup
@@ -64,6 +66,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// V (round 3; 0 = the round-2 kernel, kept for A/B through SD_XATTN_VARIANT):
+//   bit 0  phase 1: the last group of 5 MFMAs of a K tile (k-step 1 of key tiles 5-9) is issued after the NEXT barrier, from
+//          fragments carried in registers, so that a wave has matrix work the moment it leaves the barrier -- until now all
+//          eight waves first read 12 KiB of fragments each (~400 LDS cycles + latency) while the matrix pipe idled.  Same
+//          MFMAs in the same per-accumulator order: bit-identical.
+//   bit 1  phase 2: the same across the barrier between the two key halves of a tile pair (the kh = 1 stage ends in the
+//          epilogue and carries nothing).
+//   bit 2  the to_out bias reaches LDS by LDS-DMA with the first stage instead of ordinary loads + a full wait in front
+//          of the first DMA piece (the first operand tile used to land ~5 k cycles into the workgroup).
+template <int V>
 __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,9 +104,18 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
         if (p.stamps && tid == 0) p.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    // to_out bias -> LDS (before any DMA is in flight: these are the kernel's only ordinary global loads)
+    // to_out bias -> LDS.  V & 4: by LDS-DMA (C floats = C / 256 one-KiB pieces, waves 0 .. C / 256 - 1 one piece each; C is a
+    // multiple of 64, a partial last piece re-reads the vector's tail -- clamped source, identical bytes land in the slack
+    // behind sbias[C]); else ordinary loads, the kernel's only ones, retired before any DMA is in flight.
     float* sbias = (float*)(smem + BIASOFF);
-    for (int i = tid; i < C; i += 512) sbias[i] = p.bias[i];
+    if (V & 4) {
+        if (wave * 256 < C) {
+            const int i = min(wave * 256 + lane * 4, C - 4);
+            glds16(p.bias + i, (char*)sbias + wave * 1024);
+        }
+    } else {
+        for (int i = tid; i < C; i += 512) sbias[i] = p.bias[i];
+    }
 
     // ---- LDS-DMA pieces (16 rows x 64 B; lane -> row lane >> 2, chunk lane & 3, swizzled on the source) ----
     // `real` = false: nothing left to fetch -- the piece still issues (constant DMA counts, no branch) but reads 16 hot bytes
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     const int arow = hg * HKEYS * 64;
     const float c = 1.4426950408889634f;
 
-    __builtin_amdgcn_s_waitcnt(0);          // bias loads + LDS writes retired
+    if (!(V & 4)) __builtin_amdgcn_s_waitcnt(0);          // bias loads + LDS writes retired
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) piece1(0, i, smem, true);
 #pragma unroll
@@ -152,6 +173,12 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     {
         int st = 0;
         bf16x8 fa[5], fb[5], xf0, xf1;
+        // V & 1: fragments of the deferred group (k-step 1 of key tiles 5-9) of the previous K tile; zeros before the first
+        bf16x8 xfp = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (V & 1) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) fb[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
         for (int kt = 0; kt < KT; ++kt) {
             wait_vmcnt<PIECES>();                       // own pieces of tile kt landed, tile kt+1 may be in flight
             __builtin_amdgcn_s_barrier();               // ... for every wave; all waves are past tile kt-1
@@ -168,34 +195,50 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
 #pragma unroll
                 for (int t = 0; t < 5; ++t) f[t] = *(const bf16x8*)(sb + arow + (5 * (grp & 1) + t) * 2048 + fo);
             };
-            auto mm = [&](const bf16x8* f, const bf16x8& xf, int grp) {
+            auto mm = [&](const bf16x8* f, const bf16x8& xf, int grp, bool dma) {
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
                     const int tt = 5 * (grp & 1) + t;
                     S[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[t], xf, S[tt], 0, 0, 0);
                     // one DMA piece per MFMA gap (groups 0 and 1: pieces 0..2 and 3..5)
-                    if (grp < 2 && t >= 1 && t < 4) piece1(kt + 2, 3 * grp + t - 1, refill, more);
+                    if (dma && grp < 2 && t >= 1 && t < 4) piece1(kt + 2, 3 * grp + t - 1, refill, more);
                 }
             };
             xf0 = *(const bf16x8*)(sb + xrow + fo0);
             xf1 = *(const bf16x8*)(sb + xrow + fo1);
             rd(fa, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (V & 1) {
+                // the previous tile's last group first: its operands are in registers, the matrix pipe starts at once
+                mm(fb, xfp, 3, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             rd(fb, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fa, xf0, 0);
+            mm(fa, xf0, 0, true);
             __builtin_amdgcn_sched_barrier(0);
             rd(fa, 2);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fb, xf0, 1);
+            mm(fb, xf0, 1, true);
             __builtin_amdgcn_sched_barrier(0);
             rd(fb, 3);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fa, xf1, 2);
+            mm(fa, xf1, 2, true);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fb, xf1, 3);
+            if (V & 1) {
+                // group 3 is multiplied after the next barrier: its fragments must have left the LDS before this wave
+                // arrives there (the stage is refilled behind it).  The builtin, so that hipcc's wait bookkeeping knows.
+                xfp = xf1;
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+            } else {
+                mm(fb, xf1, 3, true);
+            }
             __builtin_amdgcn_sched_barrier(0);
             st = st == 2 ? 0 : st + 1;
+        }
+        if (V & 1) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) S[5 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[t], xfp, S[5 + t], 0, 0, 0);
         }
     }
     stamp(1);
@@ -277,10 +320,14 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     const int brow = hg * (32 * HKEYS * 2);                     // this wave's tile inside a stage
     const int NS = 2 * NP;
     f32x16 acc;
+    bf16x8 fa2[5], fb2[5];            // (declared outside the stage loop: V & 2 carries fb2 from a kh = 0 stage into the next)
     float ysum = 0.f, ysq = 0.f;      // LayerNorm partials of this lane's token over its channels (p.rowstats)
     int st = 0;
-    for (int s = 0; s < NS; ++s) {
-        const int pi = pbeg + (s >> 1), kh = s & 1;
+    // a stage = (tile pair, key half kh); kh is a compile-time constant of the body (the loop below runs the two stages of a
+    // pair back to back), so the carried group of V & 2 and the epilogue are straight-line code
+    auto stage = [&](const int s, auto kh_tag) {
+        constexpr int kh = decltype(kh_tag)::value;
+        const int pi = pbeg + (s >> 1);
         // Own DMA of stage s is older than stage s+1's six pieces and, after an epilogue, its two stores.
         if (kh == 0 && s > 0) wait_vmcnt<PIECES + 2>();
         else wait_vmcnt<PIECES>();
@@ -296,7 +343,6 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         }
         {
-            bf16x8 fa[5], fb[5];
             auto rd = [&](bf16x8* f, int grp) {         // 4 groups of 5 k-steps (16 key slots each)
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
@@ -304,31 +350,39 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
                     f[t] = *(const bf16x8*)(sb + (i >> 1) * 2048 + ((i & 1) ? fo1 : fo0));
                 }
             };
-            auto mm = [&](const bf16x8* f, int grp) {
+            auto mm = [&](const bf16x8* f, int grp, int khm, bool dma) {
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
                     const int i = 5 * grp + t;
-                    // global half-tile 20 kh + i: this wave's own half when kh == hg
-                    const bf16x8 pf = kh == hg ? P[i] : P[20 + i];
+                    // global half-tile 20 khm + i: this wave's own half when khm == hg
+                    const bf16x8 pf = khm == hg ? P[i] : P[20 + i];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[t], pf, acc, 0, 0, 0);
-                    if (grp < 2 && t >= 1 && t < 4) piece2(pi2, kh, 3 * grp + t - 1, refill, rst, more);
+                    if (dma && grp < 2 && t >= 1 && t < 4) piece2(pi2, kh, 3 * grp + t - 1, refill, rst, more);
                 }
             };
-            rd(fa, 0);
+            rd(fa2, 0);
             __builtin_amdgcn_sched_barrier(0);
-            rd(fb, 1);
+            if ((V & 2) && kh == 1) {                   // the kh = 0 stage's last group, carried across the barrier in fb2
+                mm(fb2, 3, 0, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rd(fb2, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fa, 0);
+            mm(fa2, 0, kh, true);
             __builtin_amdgcn_sched_barrier(0);
-            rd(fa, 2);
+            rd(fa2, 2);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fb, 1);
+            mm(fb2, 1, kh, true);
             __builtin_amdgcn_sched_barrier(0);
-            rd(fb, 3);
+            rd(fb2, 3);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fa, 2);
+            mm(fa2, 2, kh, true);
             __builtin_amdgcn_sched_barrier(0);
-            mm(fb, 3);
+            if ((V & 2) && kh == 0) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): fb2's reads have left the stage before the next barrier
+            } else {
+                mm(fb2, 3, kh, true);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (kh == 1) {
@@ -361,6 +415,10 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
             }
         }
         st = st == 2 ? 0 : st + 1;
+    };
+    for (int pr = 0; pr < NP; ++pr) {
+        stage(2 * pr, std::integral_constant<int, 0>{});
+        stage(2 * pr + 1, std::integral_constant<int, 1>{});
     }
     if (p.rowstats) {       // partial (channel slice, tile parity hg): the two lane halves hold channels 4 h + (0..3) of every 8
         ysum += __shfl_xor(ysum, 32);
@@ -397,11 +455,19 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
     SD_REQUIRE((long)KEYS * a.C * 2 * (a.M / a.rows_per_sample) < (1l << 40), "xattn: operand too large");
     static bool attr_set = false;
     if (!attr_set) {
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
+    // SD_XATTN_VARIANT: 0 = the round-2 kernel, 4 = + bias by DMA, 5 = + phase-1 cross-barrier group, 7 = + phase 2 (A/B)
+    static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 7;
     const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
-    hipLaunchKernelGGL(xattn_fused_kernel, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    if (variant == 0) hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    else if (variant == 4) hipLaunchKernelGGL(xattn_fused_kernel<4>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    else if (variant == 5) hipLaunchKernelGGL(xattn_fused_kernel<5>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(xattn_fused_kernel<7>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

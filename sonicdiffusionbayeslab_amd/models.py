@@ -95,6 +95,7 @@ class StableDiffusionModel:
         self._guidance_scale = 7.5
         self._deepcache = None          # set by DeepCacheSDHelper.enable()
         self._lora = []
+        self._fp8_calibrated = False    # fp8 handles: per-tensor activation scales are calibrated on the first call's inputs
 
     # -- loading ---------------------------------------------------------------------------
     @classmethod
@@ -272,6 +273,20 @@ class StableDiffusionModel:
             return (image, None), execution_time, image_x0
         return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0
 
+    def _calibrate_fp8_once(self, latents, unet_batch, ts_host, ctx):
+        """fp8 handles (``weight_dtype="fp8"``): the per-tensor e4m3 activation scales come from the amax observed on the
+        FIRST call's own inputs at the first, middle and last timestep of its schedule (``sd_unet_calibrate_fp8``, margin 2),
+        outside the timed loop; ``SD_AMD_FP8_CALIBRATE=0`` keeps the static defaults.  The scales then stay fixed for the
+        life of the model, so repeated calls are reproducible."""
+        if self._fp8_calibrated or self.unet.weight_dtype != "fp8_e4m3" or os.environ.get("SD_AMD_FP8_CALIBRATE", "1") == "0":
+            return
+        picks = [ts_host[0], ts_host[len(ts_host) // 2], ts_host[-1]]
+        self.unet.calibrate_fp8(latents, unet_batch, [float(t) for t in dict.fromkeys(picks)], margin=2.0)
+        self.unet.set_context(ctx)
+        self._fp8_calibrated = True
+        if "calibrated" not in self.weights_source:
+            self.weights_source += " (per-tensor e4m3 activation scales calibrated on the first call's inputs)"
+
     # -- the sampling loop (src/models.py:32-335) ----------------------------------------------
     @torch.no_grad()
     def call(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
@@ -295,6 +310,7 @@ class StableDiffusionModel:
         dc = self._deepcache
         self.unet.set_deepcache(dc.cache_branch_id if dc is not None else -1)
         self.unet.set_context(ctx)
+        self._calibrate_fp8_once(latents, unet_batch, ts_host, ctx)
         eps = self._eps_buffer(unet_batch, device)
         self._num_timesteps = len(ts_host)
         x0_preds = []

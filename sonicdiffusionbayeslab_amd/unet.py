@@ -143,6 +143,36 @@ class HipUNet2DConditionModel:
                                              cache_mode, self.cache_branch_id), "sd_unet_forward")
         return out
 
+    # -- fp8 activation-scale calibration (include/sd_hip.h::sd_unet_calibrate_fp8) ---------------------------------
+    def calibrate_fp8(self, latents: torch.Tensor, unet_batch: int, timesteps, margin: float = 2.0) -> Dict[str, float]:
+        """Per-tensor e4m3 activation scales from the amax observed on ``latents`` at each of ``timesteps`` (the context of
+        ``set_context`` is used; ``unet_batch`` as for ``forward_latents``).  Returns ``fp8_scales()``."""
+        if self.weight_dtype != "fp8_e4m3":
+            raise _lib.SdHipError("calibrate_fp8: the handle was not created with weight_dtype='fp8'")
+        if self._ctx_key is None or self._ctx_key[2] != unet_batch:
+            raise _lib.SdHipError("set_context(encoder_hidden_states) must be called for this batch first")
+        latents = latents.to(self.device, torch.float32).contiguous()
+        ws = self._workspace(unet_batch)
+        for t in timesteps:
+            _lib.check(self._lib.sd_unet_calibrate_fp8(self._handle, _lib.current_stream(), latents.data_ptr(), latents.shape[0],
+                                                       unet_batch, float(t), float(margin), self._ws_ptr(ws), ws.numel() - 256),
+                       "sd_unet_calibrate_fp8")
+        return self.fp8_scales()
+
+    def fp8_scales(self, with_amax: bool = False) -> Dict[str, float]:
+        """{tensor name: scale} of every e4m3 activation tensor known so far (``with_amax``: (scale, observed amax))."""
+        out = {}
+        name = C.create_string_buffer(256)
+        sc, am = C.c_float(), C.c_float()
+        for i in range(self._lib.sd_unet_fp8_scale_count(self._handle)):
+            _lib.check(self._lib.sd_unet_fp8_scale_info(self._handle, i, name, 256, C.byref(sc), C.byref(am)), "sd_unet_fp8_scale_info")
+            out[name.value.decode()] = (sc.value, am.value) if with_amax else sc.value
+        return out
+
+    def set_fp8_scales(self, scales: Dict[str, float]) -> None:
+        for k, v in scales.items():
+            _lib.check(self._lib.sd_unet_set_fp8_scale(self._handle, k.encode(), float(v)), f"sd_unet_set_fp8_scale({k})")
+
     KIND_NAMES = {0: "sinusoid", 1: "gemv", 2: "conv_in", 3: "groupnorm", 4: "conv3x3", 5: "gemm", 6: "layernorm",
                   7: "attention", 8: "conv_out", 16: "conv3x3_fp8", 17: "gemm_fp8", 18: "xattn_fused",
                   19: "replicate", 20: "conv3x3_gemm"}

@@ -287,10 +287,63 @@ def test_lcm_loop_fp8(small_fp8):
     out, secs, _ = model(prompt_embeds=pe, latents=lat, num_inference_steps=4, guidance_scale=0.0,
                          output_type="latent", step_noise=noise.cuda())
     assert "fp8_e4m3" in model.weights_source
+    scales = model.unet.fp8_scales(with_amax=True)       # the pipeline calibrated them on this call's inputs
+    assert scales and all(a > 0 for _, a in scales.values()) and "calibrated" in model.weights_source
     ref_q, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise,
-                                 fq=Fp8Emulation(sd))
+                                 fq=Fp8Emulation(sd, scales={k: v[0] for k, v in scales.items()}))
     ref, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise)
     e_q, e_f = rel_l2(out.images, ref_q), rel_l2(out.images, ref)
     print(f"LCM 4 steps fp8: vs emulating oracle {e_q:.3e} cos {cosine(out.images, ref_q):.5f}; vs unquantised oracle "
           f"{e_f:.3e}; loop {secs * 1e3:.1f} ms")
     assert e_q < LOOP_TOL and cosine(out.images, ref_q) > 0.99
+
+
+def test_fp8_calibration_positions_the_range(small_fp8):
+    """``sd_unet_calibrate_fp8`` (include/sd_hip.h): with the static default scale 8 an e4m3 norm output clips at
+    |x| > 56.  A checkpoint whose GroupNorm / LayerNorm gains are 30x larger than the synthetic ones (real SD-1.5 has such
+    layers) drives the norm outputs far beyond that: the default-scale forward saturates and lands far from the
+    unquantised oracle; after calibration on the same inputs every tensor's scale * amax stays below 448 and the forward is
+    back at the number format's own error.  The emulating oracle is run with the calibrated per-tensor scales."""
+    from oracle.fp8 import Fp8Emulation
+    from oracle.unet import unet_forward
+    from sonicdiffusionbayeslab_amd.unet import HipUNet2DConditionModel
+    cfg, sd0, _ = small_fp8
+    sd = dict(sd0)
+    hot = [k for k in sd if k.endswith(("resnets.0.norm2.weight", "transformer_blocks.0.norm3.weight")) and "down_blocks.1" in k]
+    assert len(hot) >= 2
+    for k in hot:
+        sd[k] = (sd[k] * 30.0).to(torch.bfloat16).float()
+    net = HipUNet2DConditionModel(cfg, sd, weight_dtype="fp8")
+    lat, pe, ne = synth_inputs(cfg, 1)
+    ctx = torch.cat([ne, pe])
+    t = 499.0
+    with torch.no_grad():
+        ref = unet_forward(sd, oracle_cfg(cfg), torch.cat([lat, lat]), t, ctx)
+    net.set_context(ctx.cuda())
+    before = net.forward_latents(lat.cuda(), 2, t).clone()
+    defaults = net.fp8_scales(with_amax=True)
+    assert all(a == 0.0 for _, a in defaults.values()) and set(s for s, _ in defaults.values()) == {8.0, 2.0}
+    scales = net.calibrate_fp8(lat.cuda(), 2, [t], margin=2.0)
+    full = net.fp8_scales(with_amax=True)
+    assert set(scales) == set(defaults) and len(scales) >= 60
+    for name, (s, amax) in full.items():
+        assert amax > 0 and s * amax <= 448.0 / 2.0 * 1.0001 and s * amax > 448.0 / 8.0, (name, s, amax)   # margin 2, power-of-two floor
+        assert s == 2.0 ** round(math.log2(s))
+    hot_names = [k[: -len(".weight")] for k in hot]
+    assert all(full[n][1] > 56.0 and full[n][0] < 8.0 for n in hot_names), [full[n] for n in hot_names]
+    net.set_context(ctx.cuda())
+    after = net.forward_latents(lat.cuda(), 2, t).clone()
+    with torch.no_grad():
+        ref_q = unet_forward(sd, oracle_cfg(cfg), torch.cat([lat, lat]), t, ctx, fq=Fp8Emulation(sd, scales=scales))
+    e_before, e_after, scheme = rel_l2(before, ref), rel_l2(after, ref), rel_l2(ref_q, ref)
+    print(f"fp8 calibration: vs unquantised oracle {e_before:.3e} with the default scales (hot layers saturate) -> {e_after:.3e} "
+          f"calibrated; emulated calibrated scheme {scheme:.3e}; HIP vs emulation {rel_l2(after, ref_q):.3e}")
+    assert e_after < 0.5 * e_before
+    assert e_after < FWD_EXCESS * scheme + 1e-2 and rel_l2(after, ref_q) < FWD_TOL
+    # a saved calibration restores bit-identical behaviour on a fresh handle
+    net2 = HipUNet2DConditionModel(cfg, sd, weight_dtype="fp8")
+    net2.set_context(ctx.cuda())
+    net2.forward_latents(lat.cuda(), 2, t)                                  # builds the plan: the tensor names exist
+    net2.set_fp8_scales(scales)
+    net2.set_context(ctx.cuda())
+    assert torch.equal(net2.forward_latents(lat.cuda(), 2, t), after)
