@@ -50,7 +50,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 __device__ __forceinline__ int swz_of(int row, int dt) { return dt ? (((row >> 1) & 1) | (row & 4)) : (row & 7); }
 
-template <int DT, int PIPE = 0>
+template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     constexpr int ESZ = DT ? 1 : 2;               // bytes per operand element; a slice = 128 / ESZ channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -204,18 +204,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     bool stores_pending = false;                  // exactly FULL_STORES stores were issued after that DMA
     constexpr int FULL_STORES = (TN / 2 + TN % 2) * TM;
 
-    // bf16 K loop, software-pipelined ACROSS the tap barrier: the 20 MFMAs of a tap's second k-step are issued after the
-    // NEXT barrier, from fragments carried in registers.  A wave then has matrix work the moment it leaves a barrier -- the
-    // first k-step's fragment reads (all eight waves read at once: ~300 LDS cycles + latency) and the DMA issue (~60-180
-    // cycles per piece, now one piece per group of 4 MFMAs: the SIMD partner multiplies meanwhile) used to idle the matrix
-    // pipe for ~500 of every ~1800 cycles.  Same MFMAs in the same per-accumulator order: bit-identical results; an item's
-    // first tap multiplies zero fragments (20 MFMAs per item), its last k-step is flushed before the epilogue.
-    // PIPE = 0: the round-2 order (SD_GEMM_TUNE bit 128, A/B).
-    constexpr bool piped = !DT && PIPE;
-#pragma unroll
-    for (int f = 0; f < TM; ++f) xf1[f] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int a = 0; a < TN; ++a) wf1[a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    // Rejected after measurement (round 3, profiles/round3_notes.md; all bit-identical to this loop): carrying the second
+    // k-step's fragments across the tap barrier so that a wave has MFMAs to issue the moment it leaves it -- for every wave
+    // (+5 % time), or only for waves 4-7, the SIMD partners of waves 0-3, as two straight-line loops (+9 %) or with
+    // wave-uniform branches inside the taps (+21 %: spills reloaded in the loop behind vmcnt(0)).  The fragment-read wait
+    // and the DMA issue after the barrier are therefore NOT what idles the matrix pipe for half of a tap.
     while (true) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
@@ -231,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             // it costs 14 spilled descriptors (tools/ab_halo.sh, same box, interleaved).  fp8: the 32-byte fragments leave
             // no room (73 spills, reloads inside the tap loop drain the counted vmcnt pipeline), so there the values are
             // made opaque per slice and the addresses are recomputed under the MFMAs.
-            if (DT || (piped && !(PIPE & 2))) {       // (PIPE = 3: keep the hoist in the pipelined loop, experiment)
+            if (DT) {
 #pragma unroll
                 for (int f = 0; f < TM; ++f) asm volatile("" : "+v"(hbase[f]), "+v"(hrc[f]));
             }
@@ -276,34 +269,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                         for (int a = 0; a < TN; ++a)
                             acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq[a], xq[b & 1], acc[a][b], 0, 0, 0, 0, 0, 0);
                     }
-                } else if (piped) {
-#pragma unroll
-                    for (int f = 0; f < TM; ++f) xf0[f] = *(const bf16x8*)(hcur + xa[f]);
-#pragma unroll
-                    for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the previous tap's second k-step (zeros on an item's first tap), one DMA piece per 4 MFMAs
-                    const int kk2 = s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1;
-#pragma unroll
-                    for (int a = 0; a < TN; ++a) {
-#pragma unroll
-                        for (int b = 0; b < TM; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[a], xf1[b], acc[a][b], 0, 0, 0);
-                        if (a == 0) { if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext); }
-                        else if (a < 4) issue_w1(a - 1, kk2, wnext);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
-#pragma unroll
-                    for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
-                    mfmas(xf0, wf0);
-                    // the second k-step's fragments are multiplied after the next barrier: they must have left the LDS before
-                    // this wave arrives there (the W stage / halo they come from is refilled behind it)
-                    // (the builtin, not inline asm: hipcc's own wait bookkeeping must know the reads have retired, or it waits
-                    // lgkmcnt(0) again in front of the carried fragments' MFMAs -- behind the NEXT tap's reads)
-                    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0), vmcnt / expcnt untouched
-                    __builtin_amdgcn_sched_barrier(0);
                 } else {
 #pragma unroll
                     for (int f = 0; f < TM; ++f) xf0[f] = *(const bf16x8*)(hcur + xa[f]);
@@ -323,14 +288,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 wst = wst == 2 ? 0 : wst + 1;
             }
             hsel ^= 1;
-        }
-
-        if (piped) {                                  // the item's last k-step; the carried fragments restart at zero
-            mfmas(xf1, wf1);
-#pragma unroll
-            for (int f = 0; f < TM; ++f) xf1[f] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int a = 0; a < TN; ++a) wf1[a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
 
         // ---- epilogue, phase A: every LOAD the epilogue needs, folded into the accumulators now so that
@@ -508,7 +465,6 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
@@ -516,8 +472,7 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     int grid = a.tiles_m * a.tiles_n * a.splitk;
     if (grid > 256) grid = 256;                  // persistent: one 8-wave workgroup per CU
     if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
-    else if (tune & 128) hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
-    else hipLaunchKernelGGL((conv_halo_kernel<0, 1>), dim3(grid), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
     if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
     return 0;

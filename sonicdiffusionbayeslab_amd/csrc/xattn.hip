@@ -73,6 +73,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 //          MFMAs in the same per-accumulator order: bit-identical.
 //   bit 1  phase 2: the same across the barrier between the two key halves of a tile pair (the kh = 1 stage ends in the
 //          epilogue and carries nothing).
+//   bit 3  phase 2: the stage of parity kh holds key half kh for tile 0 of the pair and key half kh ^ 1 for tile 1, so a wave
+//          (tile hg) multiplies its OWN probabilities at kh = 0 and the exchanged ones at kh = 1: P is indexed statically --
+//          80 v_cndmask per stage and wave (select P[i] / P[20 + i] by kh == hg) disappear.  The waves of tile 1 sum the key
+//          halves in the other order (fp32 reassociation: not bit-identical with bit 3 clear).
 //   bit 2  the to_out bias reaches LDS by LDS-DMA with the first stage instead of ordinary loads + a full wait in front
 //          of the first DMA piece (the first operand tile used to land ~5 k cycles into the workgroup).
 template <int V>
@@ -140,7 +144,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
         char* dst;
         if (i < 5) {
             const int q = wave + 8 * i, tile = q / 20, rem = q - tile * 20;
-            src = Bw + ((long)((2 * pi + tile) * 20 + 10 * kh + (rem >> 1)) * 32 + 16 * (rem & 1) + prow) * 64 + sch;
+            const int khs = (V & 8) ? (kh ^ tile) : kh;       // key half staged for this tile
+            src = Bw + ((long)((2 * pi + tile) * 20 + 10 * khs + (rem >> 1)) * 32 + 16 * (rem & 1) + prow) * 64 + sch;
             dst = st + q * 1024;
         } else {
             src = rptr + (2 * pi + kh) * 64;
@@ -354,8 +359,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
                     const int i = 5 * grp + t;
-                    // global half-tile 20 khm + i: this wave's own half when khm == hg
-                    const bf16x8 pf = khm == hg ? P[i] : P[20 + i];
+                    // global half-tile 20 khm + i: this wave's own half when khm == hg; V & 8: own half at parity 0 (static)
+                    const bf16x8 pf = (V & 8) ? P[20 * khm + i] : (khm == hg ? P[i] : P[20 + i]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[t], pf, acc, 0, 0, 0);
                     if (dma && grp < 2 && t >= 1 && t < 4) piece2(pi2, kh, 3 * grp + t - 1, refill, rst, more);
                 }
@@ -456,18 +461,15 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    // SD_XATTN_VARIANT: 0 = the round-2 kernel, 4 = + bias by DMA, 5 = + phase-1 cross-barrier group, 7 = + phase 2 (A/B)
-    static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 7;
+    // SD_XATTN_VARIANT=0: the round-2 kernel (A/B); default 15 = all round-3 changes (measured one by one on one box, 64x64
+    // launch of the bench: 72.2 us -> bias by DMA 70.9 -> + phase-1 carried group 69.9 -> + phase 2 68.5 -> + static P 68.0)
+    static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 15;
     const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
     if (variant == 0) hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
-    else if (variant == 4) hipLaunchKernelGGL(xattn_fused_kernel<4>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
-    else if (variant == 5) hipLaunchKernelGGL(xattn_fused_kernel<5>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
-    else hipLaunchKernelGGL(xattn_fused_kernel<7>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(xattn_fused_kernel<15>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -51,3 +51,14 @@ for name, v in sorted(res.items(), key=lambda kv: -(kv[1].get("SQ_VALU_MFMA_BUSY
     mb = v["mfma_busy_frac"]
     print(f"{name[:70]:70s} n={v['launches']:3d} us={v.get('avg_us_profiled', 0):8.1f} mfma_busy={mb if mb is None else round(mb, 3)} "
           f"valu_insts={v.get('SQ_INSTS_VALU', 0):.3g} lds_conf={v['lds_conflict_frac']}")
+
+# stall pass (tools/run_profiles_r3.sh stall): where the waves' cycles go, as fractions of SQ_WAVE_CYCLES
+if any("SQ_WAIT_INST_ANY" in v for v in res.values() if isinstance(v, dict)):
+    print("\nfractions of SQ_WAVE_CYCLES: parked (WAIT_ANY) | issue-stalled (WAIT_INST_ANY, of which LDS) | issuing (ACTIVE_INST_ANY: LDS, VMEM, MISC)")
+    for name, v in sorted(((n, x) for n, x in res.items() if isinstance(x, dict)), key=lambda kv: -(kv[1].get("SQ_WAVE_CYCLES") or 0) * kv[1]["launches"]):
+        w = v.get("SQ_WAVE_CYCLES") or 0
+        if not w:
+            continue
+        f = lambda k: round((v.get(k) or 0) / w, 3)
+        print(f"{name[:64]:64s} n={v['launches']:3d} us={v.get('avg_us_profiled', 0):7.1f} parked={f('SQ_WAIT_ANY')} stalled={f('SQ_WAIT_INST_ANY')} "
+              f"(lds {f('SQ_WAIT_INST_LDS')}) issuing={f('SQ_ACTIVE_INST_ANY')} (lds {f('SQ_ACTIVE_INST_LDS')} vmem {f('SQ_ACTIVE_INST_VMEM')} misc {f('SQ_ACTIVE_INST_MISC')})")
