@@ -254,6 +254,40 @@ def conv_traffic_bytes():
         return None, f"{TRAFFIC_FILE} has no hbm_bytes_per_launch"
 
 
+def conv_stream_ceiling(ub, dev):
+    """Measured ceiling of the dominant kernel's own MFMA stream: the halo conv at three of the forward's shapes with its
+    LDS-DMA, tap barriers and fragment reads removed (sd_op_conv3x3_ablate mode 8; results are wrong by design) -- every
+    v_mfma of the real kernel, nothing else -- against the unmodified kernel on the same operands.  The nominal 2.5 PFLOP/s is
+    the peak at 2.4 GHz; under a sustained MFMA load the chip holds ~1.6 GHz (MI355X_MICROARCH.md 'DVFS give-back'), and
+    this is what that leaves.  hipEvent timing on the launch stream, random bf16 operands."""
+    from sonicdiffusionbayeslab_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(7)
+    tot = {0: 0.0, 8: 0.0}
+    flops = 0.0
+    for res, c in ((64, 320), (32, 640), (16, 1280)):
+        x = torch.randn((ub, res, res, c), device=dev, generator=g).to(torch.bfloat16)
+        w = torch.randn((c, c // 64, 9, 64), device=dev, generator=g).to(torch.bfloat16)
+        y = torch.empty((ub, res, res, c), device=dev, dtype=torch.bfloat16)
+        flops += 2.0 * ub * res * res * c * 9 * c
+        for mode in (0, 8):
+            f = lambda: _lib.check(lib.sd_op_conv3x3_ablate(st, x.data_ptr(), w.data_ptr(), y.data_ptr(), ub, res, res, c, c, mode))
+            for _ in range(3):
+                f()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(10):
+                f()
+            s1.record()
+            torch.cuda.synchronize()
+            tot[mode] += s0.elapsed_time(s1) / 10 * 1e-3
+    return {"kernel_tflops": flops / tot[0] / 1e12, "bare_mfma_stream_tflops": flops / tot[8] / 1e12,
+            "kernel_over_stream": tot[8] / tot[0],
+            "what": "conv_halo_kernel at 64x64x320, 32x32x640, 16x16x1280 (UNet batch of this run), unmodified vs its bare MFMA "
+                    "stream (no LDS-DMA, barriers or fragment reads: sd_op_conv3x3_ablate 8); measured in this run"}
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh ranks with torch.distributed.run (one process
     per GPU, RCCL).  Runs BEFORE this process has touched the GPU; the parent only waits and passes the exit code on."""
@@ -444,6 +478,7 @@ def main():
                            "mfma_busy": None if fp8 else conv_mfma_busy()[0],
                            "mfma_busy_source": None if fp8 else (conv_mfma_busy()[1] or PMC_SOURCE),
                            "kernel_sources_sha16": kernel_sources_sha16(),
+                           "mfma_stream_ceiling": None if fp8 else conv_stream_ceiling(ub, dev),
                            "launches_per_forward": c3["launches"], "avg_launch_ms": c3["ms"] / max(c3["launches"], 1),
                            "flops_per_launch": c3["flops"] / max(c3["launches"], 1)}
         tot = sum(v["ms"] for v in prof.values())

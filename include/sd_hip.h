@@ -252,6 +252,11 @@ int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const
                       const float* bias, int M, int C, int rows_per_sample, int L);
 /* diagnostic twin (tools/xattn_stamps.py; no reference counterpart): same result, and the kernel stores 8 s_memtime
  * stamps per workgroup to `stamps` (caller-owned device memory, 8 * (M / 128) * slices 64-bit words) */
+/* timing ablations of the dominant kernel (the stride-1 3x3 conv with the LDS-resident halo); results are WRONG by design
+ * and Y is scratch: ablate 0 = the product kernel, 1 = no LDS-DMA waits, 2 = no LDS-DMA, 4 = no tap barrier either, 8 = no
+ * fragment reads either (the bare MFMA stream: the rate the matrix pipe sustains at the clock the chip holds under load) */
+int sd_op_conv3x3_ablate(void* stream, const void* X, const void* W, void* Y, int B, int Hin, int Win, int Cin, int Cout,
+                         int ablate);
 int sd_op_xattn_fused_stamps(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                              const float* bias, int M, int C, int rows_per_sample, int L, unsigned long long* stamps);
 

@@ -50,7 +50,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 __device__ __forceinline__ int swz_of(int row, int dt) { return dt ? (((row >> 1) & 1) | (row & 4)) : (row & 7); }
 
-template <int DT>
+// DIAG (timing ablations, WRONG results by design; SD_GEMM_TUNE bits 1 / 2 / 4, tools/conv_ab.py): 1 = the K loop never waits
+// for its LDS-DMA (vmcnt), 2 = it issues no LDS-DMA at all, 4 = no tap barrier either -- what is left of the tap time says
+// whether DMA latency, DMA issue or barrier skew parks the waves; 8 = no fragment reads either (the bare MFMA stream).
+template <int DT, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     constexpr int ESZ = DT ? 1 : 2;               // bytes per operand element; a slice = 128 / ESZ channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 // W(kt+1) -- may still be pending; on an item's first tile also the predecessor's epilogue stores,
                 // which were issued after this item's prologue DMA.  After the barrier every wave is done reading
                 // the W stage of tile kt-1 and the halo of slice s-1, which are refilled below.
+                if (DIAG == 0) {
                 if (tap == 0) {
                     if (s == s_begin && stores_pending) wait_vmcnt<3 + FULL_STORES>();
                     else wait_vmcnt<3>();
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 } else {
                     wait_vmcnt<4>();
                 }
-                __builtin_amdgcn_s_barrier();
+                }
+                if (!(DIAG & 4)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 const char* wcur = Wb + wst * WBYTES;
                 char* wnext = Wb + (wst == 0 ? 2 : wst - 1) * WBYTES;      // stage of tile kt+2 = stage of tile kt-1
@@ -270,18 +275,29 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                             acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq[a], xq[b & 1], acc[a][b], 0, 0, 0, 0, 0, 0);
                     }
                 } else {
+                    if (!(DIAG & 8)) {
 #pragma unroll
                     for (int f = 0; f < TM; ++f) xf0[f] = *(const bf16x8*)(hcur + xa[f]);
 #pragma unroll
                     for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (!(DIAG & 2)) {
                     if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
                     issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (!(DIAG & 8)) {
 #pragma unroll
                     for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
 #pragma unroll
                     for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
+                    } else if (tap == 0 && s == s_begin) {       // (MFMA-only ablation: some operand, read once per item)
+#pragma unroll
+                        for (int f = 0; f < TM; ++f) xf0[f] = xf1[f] = *(const bf16x8*)(hcur + xa[f]);
+#pragma unroll
+                        for (int a = 0; a < TN; ++a) wf0[a] = wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
+                    }
                     mfmas(xf0, wf0);
                     mfmas(xf1, wf1);
                 }
@@ -465,13 +481,22 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
+    static const int env_tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
+    const int tune = a0.tune ? a0.tune : env_tune;       // (a0.tune: sd_op_conv3x3_ablate, bench.py's measured MFMA-stream ceiling)
     a.tune = tune;
     int grid = a.tiles_m * a.tiles_n * a.splitk;
     if (grid > 256) grid = 256;                  // persistent: one 8-wave workgroup per CU
     if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
+    else if ((tune & 15) == 1) hipLaunchKernelGGL((conv_halo_kernel<0, 1>), dim3(grid), dim3(512), SMEM, stream, a);
+    else if ((tune & 15) == 2) hipLaunchKernelGGL((conv_halo_kernel<0, 3>), dim3(grid), dim3(512), SMEM, stream, a);
+    else if ((tune & 15) == 4) hipLaunchKernelGGL((conv_halo_kernel<0, 7>), dim3(grid), dim3(512), SMEM, stream, a);
+    else if ((tune & 15) == 8) hipLaunchKernelGGL((conv_halo_kernel<0, 15>), dim3(grid), dim3(512), SMEM, stream, a);
     else hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
     if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());

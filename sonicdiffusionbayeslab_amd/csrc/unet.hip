@@ -2096,6 +2096,22 @@ extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const f
     return sd_launch_conv3x3(a, (hipStream_t)stream);
 }
 
+// Timing ablations of the halo conv kernel (csrc/conv_halo.hip, template parameter DIAG; WRONG results by design, Y is
+// scratch): ablate = 1 no LDS-DMA waits, 2 no LDS-DMA at all, 4 no tap barrier either, 8 no fragment reads either = the bare
+// MFMA stream of the kernel's own tile -- the rate the matrix pipe sustains at the clock the chip holds under that load,
+// which bench.py reports next to the nominal peak.  Stride-1 shapes the halo kernel takes, no split-K.
+extern "C" int sd_op_conv3x3_ablate(void* stream, const void* X, const void* W, void* Y, int B, int Hin, int Win, int Cin, int Cout,
+                                    int ablate) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(ablate == 0 || ablate == 1 || ablate == 2 || ablate == 4 || ablate == 8, "conv3x3_ablate: mode %d", ablate);
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.C = (bf16_t*)Y; a.ldc = Cout; a.ldr = Cout;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = 1; a.up = 0; a.Hout = Hin; a.Wout = Win;
+    a.M = B * Hin * Win; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page; a.splitk = 1; a.tune = ablate;
+    SD_REQUIRE(Cin % 64 == 0 && Cout % 4 == 0 && sd_conv_halo_applicable(a), "conv3x3_ablate: not a halo-kernel shape");
+    return sd_launch_conv3x3_halo(a, (hipStream_t)stream);
+}
+
 // nearest-2x upsample + 3x3 conv computed as four 2x2 convs on the low-res input (GemmArgs::subpix); W4 =
 // [4 phases][Cout][Cin/64][4 taps][64] with the 3x3 taps that read the same low-res pixel summed (Packer::conv3_subpixel)
 extern "C" int sd_op_conv3x3_upsample_subpixel(void* stream, const void* X, const void* W4, const float* bias, void* Y, int B,
