@@ -82,13 +82,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     const int KTall = p.K / KTE;
     int split = 0, m0 = 0, n0 = 0, kt_begin = 0, KT = 0;
     auto decode = [&](int w) {
-        split = w / ntiles;
+        // (scalar work per item: keep it to two 32-bit divisions -- the 64-bit K-range arithmetic this replaced was ~250
+        // instructions per item, against ~330 in the whole K loop of a K = 320 GEMM; KTall * splitk < 2^31 by far)
+        split = p.splitk > 1 ? w / ntiles : 0;
         const int t = w - split * ntiles;
-        const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+        const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
         m0 = tile_m * BM;
         n0 = tile_n * BN;
-        kt_begin = (int)((long)KTall * split / p.splitk);
-        KT = (int)((long)KTall * (split + 1) / p.splitk) - kt_begin;
+        if (p.splitk > 1) {
+            kt_begin = KTall * split / p.splitk;
+            KT = KTall * (split + 1) / p.splitk - kt_begin;
+        } else {
+            kt_begin = 0;
+            KT = KTall;
+        }
         if (p.tune & 16) KT = 1;      // diagnostic build knob: epilogue + fixed costs only (wrong results)
     };
 

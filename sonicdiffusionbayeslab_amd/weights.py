@@ -101,6 +101,9 @@ def param_shapes(cfg: UNetConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
+_SYNTHETIC_CACHE: Dict[tuple, Dict[str, torch.Tensor]] = {}
+
+
 def make_synthetic_state_dict(cfg: UNetConfig, seed: int = 1234) -> Dict[str, torch.Tensor]:
     """Seeded SD-1.5-shaped weights, fp32 values already on the bf16 grid.
 
@@ -108,7 +111,15 @@ def make_synthetic_state_dict(cfg: UNetConfig, seed: int = 1234) -> Dict[str, to
     normalised blocks), biases ~ N(0, 0.05^2), norm gains 1 + N(0, 0.1^2), norm shifts
     N(0, 0.1^2) (non-trivial affine so parity tests exercise it).  Rounding to bf16 here means
     the CPU oracle and the HIP path consume bit-identical parameters.
+
+    The values do not depend on ``sample_size`` (no parameter shape does); generating 0.86 G Gaussians takes ~10 s, so the
+    result is cached per (architecture, seed) for the life of the process and every call returns a NEW dict over the same
+    read-only tensors (callers replace entries -- LoRA fusion, tests -- and never write into a tensor).
     """
+    key = (cfg.in_channels, cfg.out_channels, tuple(cfg.block_out_channels), cfg.layers_per_block, tuple(cfg.attn_levels),
+           cfg.cross_attention_dim, int(seed))
+    if key in _SYNTHETIC_CACHE:
+        return dict(_SYNTHETIC_CACHE[key])
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     for name, shape in param_shapes(cfg):
@@ -122,7 +133,10 @@ def make_synthetic_state_dict(cfg: UNetConfig, seed: int = 1234) -> Dict[str, to
             fan_in = math.prod(shape[1:])
             t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
         sd[name] = t.to(torch.bfloat16).float()
-    return sd
+    if len(_SYNTHETIC_CACHE) >= 2:            # (3.4 GB per SD-1.5-sized entry)
+        _SYNTHETIC_CACHE.pop(next(iter(_SYNTHETIC_CACHE)))
+    _SYNTHETIC_CACHE[key] = sd
+    return dict(sd)
 
 
 def load_unet_config(model_dir: str) -> "UNetConfig | None":
