@@ -202,3 +202,29 @@ def test_vae_decode_64_to_512_matches_oracle():
     print(f"VAE decode 64x64 -> 512x512, batch 1: rel-L2 {err:.3e} cosine {cs:.5f} max-abs {(got.cpu() - ref).abs().max():.3e}")
     assert got.shape == (1, 3, 512, 512) and torch.isfinite(got).all()
     assert err < 2e-2 and cs > 0.999
+
+
+def test_deepcache_plan_at_the_bench_batch(full_bf16):
+    """configs[3] per-GPU share (DeepCache N = 3, branch 0, batch 16 with CFG = UNet batch 32): the full-and-store step and
+    the skip step that re-uses its cache, each sample against the same pair of steps run at UNet batch 2 (the batch the
+    oracle parity of tests/test_fullsize_gpu.py covers).  Same noise-floor tolerance as (a); no oracle time."""
+    from sonicdiffusionbayeslab_amd.unet import CACHE_FULL_AND_STORE, CACHE_SKIP
+    cfg, sd, net = full_bf16
+    lat, pe, ne = synth_inputs(cfg, 16, seed=15)
+    lat2 = lat + 0.05 * synth_inputs(cfg, 16, seed=16)[0]            # the latents a step later
+    net.set_deepcache(0)
+    try:
+        net.set_context(torch.cat([ne, pe]).cuda())
+        full = net.forward_latents(lat.cuda(), 32, 981.0, cache_mode=CACHE_FULL_AND_STORE).clone()
+        skip = net.forward_latents(lat2.cuda(), 32, 961.0, cache_mode=CACHE_SKIP).clone()
+        assert torch.isfinite(full).all() and torch.isfinite(skip).all()
+        for i in (0, 9, 15):
+            net.set_context(torch.cat([ne[i:i + 1], pe[i:i + 1]]).cuda())
+            f2 = net.forward_latents(lat[i:i + 1].cuda(), 2, 981.0, cache_mode=CACHE_FULL_AND_STORE).clone()
+            s2 = net.forward_latents(lat2[i:i + 1].cuda(), 2, 961.0, cache_mode=CACHE_SKIP).clone()
+            ef = max(rel_l2(full[i:i + 1], f2[0:1]), rel_l2(full[16 + i:17 + i], f2[1:2]))
+            es = max(rel_l2(skip[i:i + 1], s2[0:1]), rel_l2(skip[16 + i:17 + i], s2[1:2]))
+            print(f"64x64 DeepCache(3,0) UNet batch 32 sample {i}: full step {ef:.3e}, skip step {es:.3e} vs its batch-2 pair of steps")
+            assert ef < BATCH_TOL and es < BATCH_TOL
+    finally:
+        net.set_deepcache(-1)
