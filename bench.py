@@ -222,14 +222,14 @@ PMC_SOURCE = (f"{PMC_FILE} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GU
 
 
 def kernel_sources_sha16():
-    """Fingerprint of the kernel sources a committed PMC profile belongs to (the GPU box has no .git): sha256 over
-    csrc/*.hip + csrc/*.h in name order, first 16 hex digits.  tools/pmc_*.py stamp it into the profile JSON and the
-    readers below refuse a profile whose stamp is not the current one (a stale counter is worse than none)."""
-    import glob
+    """Fingerprint of the kernel sources a committed PMC profile belongs to (the GPU box has no .git): sha256 over the
+    contraction kernels and their launch heuristics -- csrc/conv_halo.hip, gemm_conv.hip, xattn.hip, attention.hip, common.h,
+    kernels.h -- first 16 hex digits.  tools/pmc_*.py stamp it into the profile JSON and the readers below refuse a
+    profile whose stamp is not the current one (a stale counter is worse than none)."""
     import hashlib
     h = hashlib.sha256()
     root = os.path.join(ROOT, "sonicdiffusionbayeslab_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+    for f in [os.path.join(root, n) for n in ("attention.hip", "common.h", "conv_halo.hip", "gemm_conv.hip", "kernels.h", "xattn.hip")]:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -255,10 +255,11 @@ def conv_mfma_busy():
     d, why = _profile(PMC_FILE)
     if d is None:
         return None, why
+    rows = [v for k, v in d.items() if k.startswith("conv_halo_kernel<0") and isinstance(v, dict)]     # the bf16 product kernel
     try:
-        return float(d["conv_halo_kernel<0>"]["mfma_busy_frac"]), None
+        return float(max(rows, key=lambda v: v["launches"])["mfma_busy_frac"]), None
     except (KeyError, ValueError, TypeError):
-        return None, f"{PMC_FILE} has no conv_halo_kernel<0> row"
+        return None, f"{PMC_FILE} has no conv_halo_kernel<0, ...> row"
 
 
 def conv_traffic_bytes():

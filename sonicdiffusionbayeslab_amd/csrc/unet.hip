@@ -1990,24 +1990,31 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
     if (rc) return rc;
     SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "forward_profiled: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    // ONE event between consecutive launches (op j's time = e[j+1] - e[j]): a pair per launch put two markers between any two
+    // kernels and over-read every launch by ~10 us against the rocprofv3 kernel trace of the same forward; one marker leaves
+    // ~4-5 us (the launch latency a free-running stream hides under the previous kernel).
     std::vector<hipEvent_t> ev;
     std::vector<int> which;
+    auto mark = [&]() -> int {
+        hipEvent_t e;
+        SD_CHECK_HIP(hipEventCreate(&e));
+        SD_CHECK_HIP(hipEventRecord(e, st));
+        ev.push_back(e);
+        return 0;
+    };
+    if (mark()) return -2;
     for (size_t i = 0; i < pl->ops.size(); ++i) {
         if (cache_mode == SD_CACHE_SKIP && pl->skipped[i]) continue;
-        hipEvent_t a, b;
-        SD_CHECK_HIP(hipEventCreate(&a));
-        SD_CHECK_HIP(hipEventCreate(&b));
-        SD_CHECK_HIP(hipEventRecord(a, st));
         rc = run_op(u, *pl, pl->ops[i], (char*)workspace, latents, latent_batch, eps_out, timestep, st);
-        SD_CHECK_HIP(hipEventRecord(b, st));
-        ev.push_back(a); ev.push_back(b); which.push_back((int)i);
+        if (mark()) return -2;
+        which.push_back((int)i);
         if (rc) break;
     }
     SD_CHECK_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < SD_PROFILE_KINDS; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; kind_flops[k] = 0; kind_bytes[k] = 0; }
     for (size_t j = 0; j < which.size(); ++j) {
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[2 * j], ev[2 * j + 1]);
+        (void)hipEventElapsedTime(&ms, ev[j], ev[j + 1]);
         const Op& o = pl->ops[which[j]];
         double fl, by;
         op_work(o, &fl, &by);
