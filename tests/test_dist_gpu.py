@@ -29,7 +29,9 @@ def _run_method(config_name, nprompts, batch, overrides=None):
     from sonicdiffusionbayeslab_amd.weights import UNetConfig, make_synthetic_state_dict
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.chdir(root)
-    ucfg = UNetConfig(sample_size=16)
+    # two levels of the SD-1.5 widths: this file tests the sharding, not the kernels (a fifth of the parameters to generate,
+    # pack and upload in each of the five processes a case starts)
+    ucfg = UNetConfig(sample_size=16, block_out_channels=(320, 640), attn_levels=(True, False))
     sd = make_synthetic_state_dict(ucfg, seed=1234)
     M.StableDiffusionModel.from_pretrained = classmethod(
         lambda c, *a, **k: c(unet_config=ucfg, state_dict=dict(sd), source="synthetic(seed=1234) tiny"))
