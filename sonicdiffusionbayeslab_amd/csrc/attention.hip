@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, AttnCfg<D>::MIN_WAVES) void attn_kernel(const 
     const int head = blockIdx.y, b = blockIdx.z;
     const int q = blockIdx.x * 128 + wave * 32 + r;
     const bool qvalid = q < a.Nq;
-    const float c = a.scale * 1.4426950408889634f;
+    const float c = a.q_prescaled ? 1.0f : a.scale * 1.4426950408889634f;
 
     // ---- zero LDS once (pad columns stay zero), then plant the ones column in every V row ----
     for (int i = tid; i < Cfg::SMEM / 16; i += 256) *(u32x4*)(smem + i * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(DmaCfg<D>::NW * 64, D == 40 ? 4 : 3) void attn_dma_
     const int head = blockIdx.y, b = blockIdx.z;
     const int q = blockIdx.x * (NW * 32) + wave * 32 + r;
     const bool qvalid = q < a.Nq;
-    const float c = a.scale * 1.4426950408889634f;
+    const float c = a.q_prescaled ? 1.0f : a.scale * 1.4426950408889634f;
     const char* zero = (const char*)a.consts;
     const char* ones = zero + 256;
 
@@ -522,6 +522,20 @@ struct PipeCfg {
     static_assert(TILE >= 64 * (RSK + RSV) + 256, "slot holds the tile + the tr over-read of the last V row");
 };
 
+// V (round 3; 0 = the round-2 kernel, kept for A/B through SD_ATTN_VARIANT):
+//   bit 0  V^T fragments by inline-asm ds_read_b64_tr_b16 with hand-counted lgkmcnt waits.  hipcc cannot tell the builtin's
+//          LDS read from the LDS-DMA writes in flight and put an `s_waitcnt vmcnt(0)` in front of the first tr read of EVERY
+//          tile: the three-deep DMA ring was drained once per iteration.
+//   bit 1  the softmax reference is part of the matrix product: Q is scaled by scale * log2(e) once, and the padding column
+//          d = 40 of the QK^T contraction carries -M (M = the reference, per query, a bf16 value) against a column of ones
+//          (the h = 1 lanes of the third k-step read a {1, 0, ..} chunk instead of the over-read of the next K row), so
+//          the probabilities are exp2 of the MFMA result with no multiply-add per score, no register beyond one LDS
+//          address; and M is STALE: it moves only when a tile's maximum exceeds it by more than 2^8 (probabilities up to
+//          256 are exact in bf16 / fp32; the final division by the matrix-core row sum cancels M), so the O rescale all
+//          but disappears after the first tile.
+//   bit 2  (with bit 0) two V^T fragment register sets in turn: a group's reads are issued a whole chunk before their wait.
+#define SD_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+template <int V>
 __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const AttnArgs a) {
     using Cfg = PipeCfg;
     constexpr int D = Cfg::D, KQ = Cfg::KQ, DVT = Cfg::DVT, CD = Cfg::CD, CHK = Cfg::CHK, CHV = Cfg::CHV;
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
     const int head = blockIdx.y, b = blockIdx.z;
     const int q = blockIdx.x * (NW * 32) + wave * 32 + r;
     const bool qvalid = q < a.Nq;
-    const float c = a.scale * 1.4426950408889634f;
+    const float c = a.q_prescaled ? 1.0f : a.scale * 1.4426950408889634f;
     const char* zero = (const char*)a.consts;
     const char* ones = zero + 256;
 
@@ -547,6 +561,16 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
             const int col = kk * 16 + h * 8;
             if (qvalid && col < D) qf[kk] = *(const bf16x8*)(qp + col);
             else qf[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if ((V & 2) && !a.q_prescaled) {           // Q <- bf16(Q * scale * log2 e): S^T comes out of the MFMA in exp2 units
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                u32x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = pack2bf(bf2f((bf16_t)qf[kk][2 * j]) * c, bf2f((bf16_t)qf[kk][2 * j + 1]) * c);
+                qf[kk] = __builtin_bit_cast(bf16x8, w);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(qf[kk]));   // retire the loads before the DMA ring starts
@@ -578,6 +602,8 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
             } else if (part == CD) {
                 d_ptr[j] = ones;
             }
+        } else if (V & 2) {
+            d_ptr[j] = ones;                       // the padding piece: 64 {1, 0, ..} chunks (see kfrag2_off)
         }
     }
     const int ntiles = a.Nk / 64;                 // >= 4, all full (checked by the launcher)
@@ -603,6 +629,12 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
 
     const int kfrag_off = pi_swap23(r) * RSK + h * 16;
+    // V & 2: third k-step (columns 32..47).  h = 0: the row's columns 32..39 as before.  h = 1 (columns 40..47, Q is zero
+    // there except -M in column 40): a {1, 0, ..} chunk -- the ones chunk of V row 37 for keys 0..31, and 32 K rows
+    // (2560 B) further on a chunk of the padding piece for keys 32..63 (both immediates are shared with the h = 0 lanes)
+    static_assert(KBYTES + 37 * RSV + 2 * CD * 8 + 32 * RSK >= 11 * 1024 && KBYTES + 37 * RSV + 2 * CD * 8 + 32 * RSK + 16 <= 12 * 1024,
+                  "second ones chunk inside the padding piece");
+    const int kfrag2_off = h ? KBYTES + 37 * RSV + 2 * CD * 8 - 64 : kfrag_off;
     const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int vtr_off = KBYTES + (8 * h + q4) * RSV + (16 * g16 + 4 * p4) * 2;
 
@@ -611,8 +643,9 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         bf16x8 kf[2 * KQ];
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
-            kf[kk] = *(const bf16x8*)(kp + kk * 32);
-            kf[KQ + kk] = *(const bf16x8*)(kp + 32 * RSK + kk * 32);
+            const char* kpp = ((V & 2) && kk == KQ - 1) ? tile + kfrag2_off : kp;
+            kf[kk] = *(const bf16x8*)(kpp + kk * 32);
+            kf[KQ + kk] = *(const bf16x8*)(kpp + 32 * RSK + kk * 32);
         }
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], f32x16{}, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ], qf[0], f32x16{}, 0, 0, 0);
@@ -637,7 +670,7 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float sv = s2 < 2 ? s0[8 * s2 + j] : s1[8 * (s2 - 2) + j];
-                p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -mc));
+                p[j] = (V & 2) ? __builtin_amdgcn_exp2f(sv) : __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -mc));
             }
             u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
             pf[s2] = __builtin_bit_cast(bf16x8, w);
@@ -666,6 +699,19 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
     f32x16 sa0, sa1, sb0, sb1;                    // S(t) / S(t+1), roles swap every iteration
     qk(smem, sa0, sa1);
     float m_run = tile_max(sa0, sa1);
+    // V & 2: M = bf16(max of tile 0); -M into column 40 of Q (h = 1 lanes, first element of the third fragment)
+    auto set_ref = [&](float m) -> float {
+        const unsigned pb = pack2bf(-m, 0.f) & 0xffffu;
+        if (h) qf[KQ - 1][0] = (short)pb;
+        return -bf2f((bf16_t)pb);
+    };
+    if (V & 2) {
+        m_run = set_ref(m_run);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sa0[i] -= m_run; sa1[i] -= m_run; }
+    }
+    constexpr float STALE = 8.f;                  // log2 of the largest probability before M is moved
+    const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)vtr_off;
 
     // One steady-state iteration (t <= ntiles - 2): consumes S(t) in (c0, c1), produces S(t+1) in (n0, n1).
     // Hand-interleaved in seven fenced chunks so that every chunk carries matrix AND vector work of one wave:
@@ -674,6 +720,12 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
     //   chunks 4-6: two PV MFMAs with P group 1, 2, 3  +  the running max over S(t+1)
     auto exp_group = [&](const f32x16& c0, const f32x16& c1, int s2, float mc) -> bf16x8 {
         float p[8];
+        if (V & 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f(s2 < 2 ? c0[8 * s2 + j] : c1[8 * (s2 - 2) + j]);
+            u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+            return __builtin_bit_cast(bf16x8, w);
+        }
         const f32x2_t cc = {c, c}, mm = {-mc, -mc};
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {          // s*c - m*c two scores at a time: v_pk_fma_f32
@@ -699,14 +751,32 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         issue(t + 3);
         const char* cur = smem + (t & 3) * TILE;
         const char* kp = smem + ((t + 1) & 3) * TILE + kfrag_off;
+        const char* kp2 = (V & 2) ? smem + ((t + 1) & 3) * TILE + kfrag2_off : kp;
         const float mc = m_run * c;
         bf16x8 kf[2 * KQ];
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
-            kf[kk] = *(const bf16x8*)(kp + kk * 32);
-            kf[KQ + kk] = *(const bf16x8*)(kp + 32 * RSK + kk * 32);
+            const char* kpp = kk == KQ - 1 ? kp2 : kp;
+            kf[kk] = *(const bf16x8*)(kpp + kk * 32);
+            kf[KQ + kk] = *(const bf16x8*)(kpp + 32 * RSK + kk * 32);
         }
         bf16x8 pf[4], va, vb;
+        // V & 1: V^T fragments of P group G by inline asm into register set S = x / y (4 reads: tile 0 lo, hi, tile 1 lo, hi);
+        // READY_A / READY_B: the tile-0 / tile-1 fragment has landed when at most N LDS operations issued after it are
+        // outstanding.  V & 4: two sets in turn, group G + 1 is requested BEFORE the wait for group G (else the four
+        // waits per tile expose the LDS latency to this wave); without bit 2 one set, requested after the previous MFMAs.
+        const unsigned vaddr = lds_v + (unsigned)((t & 3) * TILE);
+        bf16x4 xal, xah, xbl, xbh, yal, yah, ybl, ybh;
+#define SD_VREAD(S, G)                                                                                     \
+        SD_TR_READ(S##al, vaddr, (G) * 16 * RSV); SD_TR_READ(S##ah, vaddr, (G) * 16 * RSV + 4 * RSV);      \
+        SD_TR_READ(S##bl, vaddr, (G) * 16 * RSV + 64); SD_TR_READ(S##bh, vaddr, (G) * 16 * RSV + 64 + 4 * RSV);
+#define SD_VREADY_A(S, N)                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(S##al), "+v"(S##ah) : "n"(N));                        \
+        va = bf16x8{S##al[0], S##al[1], S##al[2], S##al[3], S##ah[0], S##ah[1], S##ah[2], S##ah[3]};
+#define SD_VREADY_B(S, N)                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(S##bl), "+v"(S##bh), "+v"(o[0]) : "n"(N));            \
+        vb = bf16x8{S##bl[0], S##bl[1], S##bl[2], S##bl[3], S##bh[0], S##bh[1], S##bh[2], S##bh[3]};
+        constexpr bool ASM = V & 1, PING = (V & 5) == 5;
         __builtin_amdgcn_sched_barrier(0);
         n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], f32x16{}, 0, 0, 0);
         n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ], qf[0], f32x16{}, 0, 0, 0);
@@ -716,36 +786,73 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 1], qf[1], n1, 0, 0, 0);
         pf[1] = exp_group(c0, c1, 1, mc);
         __builtin_amdgcn_sched_barrier(0);
+        if (PING) { SD_VREAD(x, 0) __builtin_amdgcn_sched_barrier(0); }
         n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[2], n0, 0, 0, 0);
         n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 2], qf[2], n1, 0, 0, 0);
         pf[2] = exp_group(c0, c1, 2, mc);
-        va = vfrag(cur, 0, 0); vb = vfrag(cur, 1, 0);
+        if (!ASM) { va = vfrag(cur, 0, 0); vb = vfrag(cur, 1, 0); }
+        else if (!PING) { SD_VREAD(x, 0) }
         __builtin_amdgcn_sched_barrier(0);
+        if (PING) { SD_VREAD(y, 1) SD_VREADY_A(x, 6) }
+        else if (ASM) { SD_VREADY_A(x, 2) }
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[0], o[0], 0, 0, 0);
+        if (PING) { SD_VREADY_B(x, 4) }
+        else if (ASM) { SD_VREADY_B(x, 0) }
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[0], o[1], 0, 0, 0);
         pf[3] = exp_group(c0, c1, 3, mc);
-        va = vfrag(cur, 0, 1); vb = vfrag(cur, 1, 1);
+        if (!ASM) { va = vfrag(cur, 0, 1); vb = vfrag(cur, 1, 1); }
+        else if (!PING) { SD_VREAD(x, 1) }
         __builtin_amdgcn_sched_barrier(0);
+        if (PING) { SD_VREAD(x, 2) SD_VREADY_A(y, 6) }
+        else if (ASM) { SD_VREADY_A(x, 2) }
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[1], o[0], 0, 0, 0);
+        if (PING) { SD_VREADY_B(y, 4) }
+        else if (ASM) { SD_VREADY_B(x, 0) }
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[1], o[1], 0, 0, 0);
         float tm0 = fmaxf(n0[0], n1[0]);
 #pragma unroll
-        for (int i = 1; i < 8; ++i) tm0 = fmaxf(tm0, fmaxf(n0[i], n1[i]));
-        va = vfrag(cur, 0, 2); vb = vfrag(cur, 1, 2);
+        for (int i = 1; i < 8; ++i) tm0 = (V & 2) ? fmaxf(fmaxf(tm0, n0[i]), n1[i]) : fmaxf(tm0, fmaxf(n0[i], n1[i]));
+        if (!ASM) { va = vfrag(cur, 0, 2); vb = vfrag(cur, 1, 2); }
+        else if (!PING) { SD_VREAD(x, 2) }
         __builtin_amdgcn_sched_barrier(0);
+        if (PING) { SD_VREAD(y, 3) SD_VREADY_A(x, 6) }
+        else if (ASM) { SD_VREADY_A(x, 2) }
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[2], o[0], 0, 0, 0);
+        if (PING) { SD_VREADY_B(x, 4) }
+        else if (ASM) { SD_VREADY_B(x, 0) }
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[2], o[1], 0, 0, 0);
 #pragma unroll
-        for (int i = 8; i < 16; ++i) tm0 = fmaxf(tm0, fmaxf(n0[i], n1[i]));
-        va = vfrag(cur, 0, 3); vb = vfrag(cur, 1, 3);
+        for (int i = 8; i < 16; ++i) tm0 = (V & 2) ? fmaxf(fmaxf(tm0, n0[i]), n1[i]) : fmaxf(tm0, fmaxf(n0[i], n1[i]));
+        if (!ASM) { va = vfrag(cur, 0, 3); vb = vfrag(cur, 1, 3); }
+        else if (!PING) { SD_VREAD(x, 3) }
         __builtin_amdgcn_sched_barrier(0);
+        if (PING) { SD_VREADY_A(y, 2) }
+        else if (ASM) { SD_VREADY_A(x, 2) }
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[3], o[0], 0, 0, 0);
+        if (PING) { SD_VREADY_B(y, 0) }
+        else if (ASM) { SD_VREADY_B(x, 0) }
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[3], o[1], 0, 0, 0);
         const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tm0),
                                                          __builtin_bit_cast(unsigned, tm0), false, false);
-        const float m_new = fmaxf(m_run, fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])));
+        const float tmx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        const float m_new = fmaxf(m_run, tmx);
         __builtin_amdgcn_sched_barrier(0);
-        if (!__all(m_new == m_run)) {
+        if (V & 2) {
+            // tmx is relative to M (the MFMAs started at -M).  Rare: some query's tile maximum is more than 2^STALE above
+            // its reference -> every lane moves M up to its tile maximum (if that is above M at all)
+            if (!__all(tmx <= STALE)) {
+                const float m_old = m_run;
+                m_run = set_ref(m_run + fmaxf(tmx, 0.f));
+                const float d = m_run - m_old;
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                for (int tt = 0; tt < DVT; ++tt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[tt][i] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { n0[i] -= d; n1[i] -= d; }
+            }
+        } else if (!__all(m_new == m_run)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
 #pragma unroll
             for (int tt = 0; tt < DVT; ++tt)
@@ -762,6 +869,9 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         softmax_p(c0, c1, m_run * c, pf);
         pv(smem + (t & 3) * TILE, pf);
     };
+#undef SD_VREAD
+#undef SD_VREADY_A
+#undef SD_VREADY_B
     int t = 0;
     for (; t + 2 < ntiles; t += 2) {
         steady(t, sa0, sa1, sb0, sb1);
@@ -797,12 +907,21 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
 int launch_attn_pipe40(const AttnArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe40_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe40_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe40_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe40_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe40_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
         attr_set = true;
     }
     constexpr int QB = PipeCfg::NW * 32;
     dim3 grid((a.Nq + QB - 1) / QB, a.heads, a.B);
-    hipLaunchKernelGGL(attn_pipe40_kernel, grid, dim3(PipeCfg::NW * 64), PipeCfg::SMEM, stream, a);
+    // SD_ATTN_VARIANT: 0 = the round-2 kernel, bits see the kernel (A/B: 0, 1, 3, 7)
+    static const int variant = getenv("SD_ATTN_VARIANT") ? atoi(getenv("SD_ATTN_VARIANT")) & 7 : 7;
+    const dim3 blk(PipeCfg::NW * 64);
+    if (variant == 0) hipLaunchKernelGGL(attn_pipe40_kernel<0>, grid, blk, PipeCfg::SMEM, stream, a);
+    else if (variant == 1) hipLaunchKernelGGL(attn_pipe40_kernel<1>, grid, blk, PipeCfg::SMEM, stream, a);
+    else if (variant == 3) hipLaunchKernelGGL(attn_pipe40_kernel<3>, grid, blk, PipeCfg::SMEM, stream, a);
+    else hipLaunchKernelGGL(attn_pipe40_kernel<7>, grid, blk, PipeCfg::SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

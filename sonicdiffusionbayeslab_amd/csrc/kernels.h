@@ -125,6 +125,9 @@ struct AttnArgs {
     // HEAD-MAJOR K / V ([B][heads][Nk][D] contiguous: a 64-key tile of one head is 64 * D * 2 contiguous bytes, so the
     // LDS-DMA pieces of the 64x64 self-attention touch 8 cache lines instead of ~26); 0 = token-major as Q (ldk / ldv)
     int kv_head_major = 0;
+    // Q already carries scale * log2(e) (the UNet folds it into W_q before the weight's one rounding): the kernels take
+    // the QK^T product as the exp2 argument as it is; `scale` is then ignored
+    int q_prescaled = 0;
 };
 int sd_launch_attention(const AttnArgs& a, hipStream_t stream);
 

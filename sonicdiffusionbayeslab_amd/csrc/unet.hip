@@ -122,6 +122,7 @@ struct Op {
     // this GEMM normalises with (its x1 is the un-normalised tensor, its weights carry gamma, its bias W beta + b)
     int subpix = 0;                   // CONV3 with up: four 2x2 convs on the low-res input (GemmArgs::subpix)
     int hm = 0;                       // GEMM: q|k|v with head-major K / V (HW = tokens per sample); ATTN: K / V are head-major
+    int qps = 0;                      // ATTN: Q arrives multiplied by scale * log2 e (folded into W_q at pack time)
     int rs = -1, lnrs = -1, lnnp = 0;
     size_t c1 = NOFF;
     size_t wsc = NOFF;
@@ -479,9 +480,11 @@ struct Packer {
         }
     }
     void fp8_same(const std::string& n, int N, int K) { quant_rows(n, P(n).data(), N, K, (K + 127) / 128 * 128); }
-    void fp8_concat_rows(const std::string& key, const std::vector<std::string>& names, int K) {
+    // scale0: factor on the rows of the FIRST matrix (the self-attention's to_q carries softmax scale * log2 e, see qscale())
+    void fp8_concat_rows(const std::string& key, const std::vector<std::string>& names, int K, float scale0 = 1.f) {
         std::vector<float> all;
         for (auto& n : names) all.insert(all.end(), P(n).begin(), P(n).end());
+        for (size_t i = 0; i < P(names[0]).size(); ++i) all[i] *= scale0;
         quant_rows(key, all.data(), (int)(all.size() / K), K, (K + 127) / 128 * 128);
     }
     // OIHW -> e4m3 [O][Ip/128][tap][128] (Ip = I padded to 128) + per-output-channel scale
@@ -570,13 +573,13 @@ struct Packer {
                 for (int t = 0; t < 9; ++t)
                     o[((size_t)oc * 9 + t) * I + ic] = f32_to_bf16_host(d[((size_t)oc * I + ic) * 9 + t]);
     }
-    void concat_rows(const std::string& key, const std::vector<std::string>& names) {
+    void concat_rows(const std::string& key, const std::vector<std::string>& names, float scale0 = 1.f) {
         size_t total = 0;
         for (auto& n : names) total += P(n).size();
         size_t off = alloc(key, total * 2);
         unsigned short* o = (unsigned short*)(u->hblob.data() + off);
         for (auto& n : names)
-            for (float v : P(n)) *o++ = f32_to_bf16_host(v);
+            for (float v : P(n)) *o++ = f32_to_bf16_host(&n == &names[0] ? v * scale0 : v);
     }
     // LayerNorm folded into the GEMM that consumes it (GemmArgs::ln_rs): rows [N][K] fp32 -> key.ln = bf16(W * gamma),
     // key.c1[n] = sum_k of the ROUNDED row (what the kernel's raw sums contain per unit of the row mean),
@@ -693,17 +696,21 @@ struct Packer {
         f32(p + "proj_in.bias");
         const std::string t = p + "transformer_blocks.0.";
         for (int i = 1; i <= 3; ++i) { f32(t + "norm" + std::to_string(i) + ".weight"); f32(t + "norm" + std::to_string(i) + ".bias"); }
+        // The self-attention's softmax scale and the exp -> exp2 factor live in W_q (fp32, before the one rounding every weight
+        // gets): S = (c W_q x) . k comes out of the attention kernels' QK^T product in exp2 units (AttnArgs::q_prescaled)
+        const float qs = 1.4426950408889634f / sqrtf((float)(c / u->cfg.num_heads));
         if (u->fp8) {
             fp8_same(p + "proj_in.weight", c, c);
-            fp8_concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"}, c);
+            fp8_concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"}, c, qs);
             fp8_same(t + "ff.net.2.weight", c, 4 * c);
         } else {
             bf16_same(p + "proj_in.weight");
-            concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"});
+            concat_rows(t + "attn1.qkv.weight", {t + "attn1.to_q.weight", t + "attn1.to_k.weight", t + "attn1.to_v.weight"}, qs);
             {   // norm1 folded into the q|k|v projection
                 std::vector<float> all;
                 for (const char* n : {"attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight"})
                     all.insert(all.end(), P(t + n).begin(), P(t + n).end());
+                for (size_t i = 0; i < (size_t)c * c; ++i) all[i] *= qs;
                 ln_fold(t + "attn1.qkv.weight", all.data(), 3 * c, c, P(t + "norm1.weight"), P(t + "norm1.bias"), nullptr);
             }
             bf16_same(t + "ff.net.2.weight");
@@ -1085,6 +1092,7 @@ struct Builder {
         } else {
             a1 = attn(qkv, 0, 3 * C, qkv, C, 2 * C, 3 * C, hw, hw, C);
         }
+        pl.ops.back().qps = 1;          // W_q of attn1 carries the scale (Packer::transformer)
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
         if (prefix_rep > 1) {        // end of the prompt-independent prefix: both CFG halves continue from copies
             x = replicate(x, (size_t)M * C * 2, prefix_rep);
@@ -1528,6 +1536,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.O = (bf16_t*)T(o.out); a.ldo = o.ldo;
             a.B = o.B; a.heads = o.heads; a.Nq = o.Nq; a.Nk = o.Nk; a.D = o.D;
             a.scale = 1.0f / sqrtf((float)o.D);
+            a.q_prescaled = o.qps;
             a.consts = g_zero_page;
             a.kv_head_major = o.hm;
             return sd_launch_attention(a, stream);

@@ -61,6 +61,8 @@ constexpr int SMEM = BIASOFF + MAXC * 4;    // 157 KiB
 static_assert(RING <= BIASOFF && EXOFF + 8 * 10240 <= ROFF && SMEM <= 160 * 1024, "LDS budget");
 constexpr int PIECES = 6;                   // 1-KiB DMA pieces per wave and stage, both phases
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -169,11 +171,14 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     for (int i = 0; i < PIECES; ++i) piece1(1, i, smem + STAGE1, KT > 1);
 
     // =============================== phase 1: S^T = A^T . X^T (this wave's 4 heads) ===============================
+    // V & 16: no zeroing of the 160 accumulators -- the first K tile's first k-step multiplies onto a constant-zero C operand
     f32x16 S[NKT];
+    if (!(V & 16)) {
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
+        for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+            for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+        }
     }
     {
         int st = 0;
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
 #pragma unroll
             for (int t = 0; t < 5; ++t) fb[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        for (int kt = 0; kt < KT; ++kt) {
+        auto ktile = [&](int kt, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;        // K tile 0 of a V & 16 kernel
             wait_vmcnt<PIECES>();                       // own pieces of tile kt landed, tile kt+1 may be in flight
             __builtin_amdgcn_s_barrier();               // ... for every wave; all waves are past tile kt-1
             asm volatile("" ::: "memory");
@@ -204,7 +210,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
                     const int tt = 5 * (grp & 1) + t;
-                    S[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[t], xf, S[tt], 0, 0, 0);
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    S[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[t], xf, FIRST && grp < 2 ? zero : S[tt], 0, 0, 0);
                     // one DMA piece per MFMA gap (groups 0 and 1: pieces 0..2 and 3..5)
                     if (dma && grp < 2 && t >= 1 && t < 4) piece1(kt + 2, 3 * grp + t - 1, refill, more);
                 }
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
             xf1 = *(const bf16x8*)(sb + xrow + fo1);
             rd(fa, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (V & 1) {
+            if ((V & 1) && !FIRST) {
                 // the previous tile's last group first: its operands are in registers, the matrix pipe starts at once
                 mm(fb, xfp, 3, false);
                 __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
             }
             __builtin_amdgcn_sched_barrier(0);
             st = st == 2 ? 0 : st + 1;
-        }
+        };
+        if (V & 16) ktile(0, std::true_type{});
+        for (int kt = (V & 16) ? 1 : 0; kt < KT; ++kt) ktile(kt, std::false_type{});
         if (V & 1) {
 #pragma unroll
             for (int t = 0; t < 5; ++t) S[5 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[t], xfp, S[5 + t], 0, 0, 0);
@@ -278,17 +287,45 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mc = mx * c;
         float sum = 0.f;
+        if (V & 16) {
+            // packed f32 pairs (v_pk_fma / v_pk_add / v_pk_mul): half the VALU issue slots of the scalar chain, and four
+            // independent partial sums instead of one 40-deep dependent add chain
+            f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+            const f32x2 cc = {c, c}, mm2 = {-mc, -mc};
 #pragma unroll
-        for (int i = 0; i < 40; ++i) {
-            v[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[i], c, -mc));
-            sum += v[i];
+            for (int i = 0; i < 40; i += 4) {
+                const f32x2 a = __builtin_elementwise_fma(f32x2{v[i], v[i + 1]}, cc, mm2);
+                const f32x2 b = __builtin_elementwise_fma(f32x2{v[i + 2], v[i + 3]}, cc, mm2);
+                const f32x2 ea = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                const f32x2 eb = {__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+                s0 += ea;
+                s1 += eb;
+                v[i] = ea[0], v[i + 1] = ea[1], v[i + 2] = eb[0], v[i + 3] = eb[1];
+            }
+            s0 += s1;
+            sum = s0[0] + s0[1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 40; ++i) {
+                v[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[i], c, -mc));
+                sum += v[i];
+            }
         }
         sum += __shfl_xor(sum, 32);
         const float inv = __builtin_amdgcn_rcpf(sum);
+        if (V & 16) {
+            const f32x2 ii = {inv, inv};
+#pragma unroll
+            for (int i = 0; i < 40; i += 2) {
+                const f32x2 t = f32x2{v[i], v[i + 1]} * ii;
+                v[i] = t[0], v[i + 1] = t[1];
+            }
+        }
+        const float inv1 = (V & 16) ? 1.f : inv;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const u32x4 pk = {pack2bf(v[q * 8 + 0] * inv, v[q * 8 + 1] * inv), pack2bf(v[q * 8 + 2] * inv, v[q * 8 + 3] * inv),
-                              pack2bf(v[q * 8 + 4] * inv, v[q * 8 + 5] * inv), pack2bf(v[q * 8 + 6] * inv, v[q * 8 + 7] * inv)};
+            const u32x4 pk = {pack2bf(v[q * 8 + 0] * inv1, v[q * 8 + 1] * inv1), pack2bf(v[q * 8 + 2] * inv1, v[q * 8 + 3] * inv1),
+                              pack2bf(v[q * 8 + 4] * inv1, v[q * 8 + 5] * inv1), pack2bf(v[q * 8 + 6] * inv1, v[q * 8 + 7] * inv1)};
             P[5 * hd + q] = __builtin_bit_cast(bf16x8, pk);     // local half-tile index; global = 20 hg + local
         }
     }
@@ -462,14 +499,16 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<31>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     // SD_XATTN_VARIANT=0: the round-2 kernel (A/B); default 15 = all round-3 changes (measured one by one on one box, 64x64
     // launch of the bench: 72.2 us -> bias by DMA 70.9 -> + phase-1 carried group 69.9 -> + phase 2 68.5 -> + static P 68.0)
-    static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 15;
+    static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 31;
     const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
     if (variant == 0) hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
-    else hipLaunchKernelGGL(xattn_fused_kernel<15>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    else if (variant == 15) hipLaunchKernelGGL(xattn_fused_kernel<15>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(xattn_fused_kernel<31>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

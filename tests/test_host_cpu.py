@@ -394,9 +394,11 @@ def test_finalize_packs_weights_on_the_host(dtype):
                     for dx in (0, 1):
                         want = wu[:, :, rows[py][dy]][:, :, :, rows[px][dx]].sum((2, 3)).bfloat16()      # [O, I]
                         assert torch.equal(got[py * 2 + px, :, :, dy * 2 + dx, :].reshape(640, 640), want)
-        # LayerNorm folded into q|k|v: rows bf16(W gamma), c1 = sum of the ROUNDED row, c2 = W beta
+        # LayerNorm folded into q|k|v: rows bf16(W gamma), c1 = sum of the ROUNDED row, c2 = W beta; the W_q rows carry the
+        # softmax scale and the exp -> exp2 factor, log2(e) / sqrt(head_dim), multiplied in fp32 before the rounding
         g1, be1 = sd[t + "norm1.weight"].float(), sd[t + "norm1.bias"].double()
         rows = torch.cat([sd[t + f"attn1.to_{x}.weight"] for x in "qkv"]).float()
+        rows[:320] *= (torch.tensor(1.4426950408889634, dtype=torch.float32) / torch.sqrt(torch.tensor(40.0, dtype=torch.float32)))
         got = packed(t + "attn1.qkv.weight.ln", 960 * 320 * 2, torch.bfloat16).view(960, 320)
         assert torch.equal(got, (rows * g1[None, :]).bfloat16())
         assert torch.allclose(packed(t + "attn1.qkv.weight.c1", 960 * 4, torch.float32), got.double().sum(1).float(), rtol=1e-6, atol=1e-6)
@@ -420,7 +422,8 @@ def test_finalize_packs_weights_on_the_host(dtype):
         assert same_codes(got[:, :320], want) and (got[:, 320:] == 0).all()
         assert torch.equal(packed(t + "ff.geglu.weight.scale", 2 * H * 4, torch.float32), sc[idx])
         # fused QKV rows of the self-attention
-        rows = torch.cat([sd[t + f"attn1.to_{x}.weight"] for x in "qkv"])
+        rows = torch.cat([sd[t + f"attn1.to_{x}.weight"] for x in "qkv"]).float()
+        rows[:320] *= (torch.tensor(1.4426950408889634, dtype=torch.float32) / torch.sqrt(torch.tensor(40.0, dtype=torch.float32)))    # W_q carries scale * log2 e
         wq, sc = quantize_rows(rows)
         got = packed(t + "attn1.qkv.weight.fp8", 960 * 384, torch.uint8).view(960, 384)
         assert same_codes(got[:, :320], wq.to(torch.float8_e4m3fn).view(torch.uint8)) and (got[:, 320:] == 0).all()
