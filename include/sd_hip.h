@@ -165,6 +165,12 @@ int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int
                              int cache_branch_id, double kind_ms[SD_PROFILE_KINDS], long long kind_launches[SD_PROFILE_KINDS],
                              double kind_flops[SD_PROFILE_KINDS], double kind_bytes[SD_PROFILE_KINDS]);
 
+/* The same measurement, one text line per launch: "op-index kind M N K milliseconds GFLOP MB" (kinds as above before the
+ * 16+ regrouping; development: which shapes carry a group's time).  Returns the bytes written to `text`, < 0 on error. */
+long long sd_unet_forward_op_times(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                                   float timestep, float* eps_out, void* workspace, long long workspace_bytes, int cache_mode,
+                                   int cache_branch_id, char* text, long long cap);
+
 /* Debug/parity hook: copy a named intermediate (bf16 NHWC) of the LAST full forward into `out`
  * as fp32; names: "conv_in", "down0".."down3", "mid", "up0".."up3".  Synchronises the stream. */
 int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host_out, long long numel,

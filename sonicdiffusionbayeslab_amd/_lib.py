@@ -69,6 +69,7 @@ _SIGS = {
     "sd_unet_forward": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _ll, _i, _i]),
     "sd_unet_forward_profiled": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _ll, _i, _i, C.POINTER(C.c_double),
                                       C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sd_unet_forward_op_times": (_ll, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _ll, _i, _i, C.c_char_p, _ll]),
     "sd_vae_create": (_i, [C.POINTER(SdUnetConfig), C.POINTER(_vp)]),
     "sd_vae_decode": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _ll]),
     "sd_clip_create": (_i, [C.POINTER(SdClipConfig), C.POINTER(_vp)]),

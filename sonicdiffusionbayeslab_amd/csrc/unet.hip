@@ -1984,24 +1984,22 @@ static void op_work(const Op& o, double* flops, double* bytes) {
     }
 }
 
-extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
-                                        float timestep, float* eps_out, void* workspace, long long workspace_bytes,
-                                        int cache_mode, int cache_branch_id, double kind_ms[SD_PROFILE_KINDS],
-                                        long long kind_launches[SD_PROFILE_KINDS], double kind_flops[SD_PROFILE_KINDS],
-                                        double kind_bytes[SD_PROFILE_KINDS]) {
-    SD_REQUIRE(latents && eps_out && workspace && kind_ms && kind_launches && kind_flops && kind_bytes,
-               "forward_profiled: null argument");
+// One forward with ONE event between consecutive launches (op j's time = e[j+1] - e[j]): a pair per launch put two markers
+// between any two kernels and over-read every launch by ~10 us against the rocprofv3 kernel trace of the same forward; one
+// marker leaves ~4-5 us (the launch latency a free-running stream hides under the previous kernel).
+static int profiled_run(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch, float timestep,
+                        float* eps_out, void* workspace, long long workspace_bytes, int cache_mode, int cache_branch_id,
+                        Plan** plan, std::vector<std::pair<int, float>>* per_op) {
+    SD_REQUIRE(latents && eps_out && workspace, "forward_profiled: null argument");
     SD_REQUIRE(latent_batch > 0 && unet_batch % latent_batch == 0, "forward_profiled: bad batch");
     Plan* pl;
     const int rep = plan_rep(u, latent_batch, unet_batch);
     u->last_rep = rep;
     int rc = get_plan(u, unet_batch, cache_branch_id, &pl, rep);
     if (rc) return rc;
+    *plan = pl;
     SD_REQUIRE((long long)pl->total_bytes <= workspace_bytes, "forward_profiled: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    // ONE event between consecutive launches (op j's time = e[j+1] - e[j]): a pair per launch put two markers between any two
-    // kernels and over-read every launch by ~10 us against the rocprofv3 kernel trace of the same forward; one marker leaves
-    // ~4-5 us (the launch latency a free-running stream hides under the previous kernel).
     std::vector<hipEvent_t> ev;
     std::vector<int> which;
     auto mark = [&]() -> int {
@@ -2020,11 +2018,29 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
         if (rc) break;
     }
     SD_CHECK_HIP(hipStreamSynchronize(st));
-    for (int k = 0; k < SD_PROFILE_KINDS; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; kind_flops[k] = 0; kind_bytes[k] = 0; }
     for (size_t j = 0; j < which.size(); ++j) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, ev[j], ev[j + 1]);
-        const Op& o = pl->ops[which[j]];
+        per_op->push_back({which[j], ms});
+    }
+    for (auto e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                                        float timestep, float* eps_out, void* workspace, long long workspace_bytes,
+                                        int cache_mode, int cache_branch_id, double kind_ms[SD_PROFILE_KINDS],
+                                        long long kind_launches[SD_PROFILE_KINDS], double kind_flops[SD_PROFILE_KINDS],
+                                        double kind_bytes[SD_PROFILE_KINDS]) {
+    SD_REQUIRE(kind_ms && kind_launches && kind_flops && kind_bytes, "forward_profiled: null argument");
+    Plan* pl = nullptr;
+    std::vector<std::pair<int, float>> per_op;
+    const int rc = profiled_run(u, stream, latents, latent_batch, unet_batch, timestep, eps_out, workspace, workspace_bytes,
+                                cache_mode, cache_branch_id, &pl, &per_op);
+    if (!pl) return rc;
+    for (int k = 0; k < SD_PROFILE_KINDS; ++k) { kind_ms[k] = 0; kind_launches[k] = 0; kind_flops[k] = 0; kind_bytes[k] = 0; }
+    for (auto& [i, ms] : per_op) {
+        const Op& o = pl->ops[i];
         double fl, by;
         op_work(o, &fl, &by);
         // (20: the convs that run on the implicit-GEMM kernel -- stride 2 and the sub-pixel upsamplers -- apart from the halo kernel's)
@@ -2033,8 +2049,31 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
                        (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
         kind_ms[kd] += ms; kind_launches[kd] += 1; kind_flops[kd] += fl; kind_bytes[kd] += by;
     }
-    for (auto e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+// The same measurement, one text line per launch: "index kind M N K ms GFLOP MB" (development: which shapes carry a group's
+// time).  Returns the number of bytes written (without the terminator), < 0 on error.
+extern "C" long long sd_unet_forward_op_times(sd_unet* u, void* stream, const float* latents, int latent_batch, int unet_batch,
+                                              float timestep, float* eps_out, void* workspace, long long workspace_bytes,
+                                              int cache_mode, int cache_branch_id, char* text, long long cap) {
+    SD_REQUIRE(text && cap > 0, "forward_op_times: null argument");
+    Plan* pl = nullptr;
+    std::vector<std::pair<int, float>> per_op;
+    const int rc = profiled_run(u, stream, latents, latent_batch, unet_batch, timestep, eps_out, workspace, workspace_bytes,
+                                cache_mode, cache_branch_id, &pl, &per_op);
+    if (rc) return rc;
+    long long n = 0;
+    for (auto& [i, ms] : per_op) {
+        const Op& o = pl->ops[i];
+        double fl, by;
+        op_work(o, &fl, &by);
+        const int w = snprintf(text + n, (size_t)(cap - n), "%d %d %d %d %d %.5f %.3f %.3f\n", i, (int)o.kind, o.M, o.N, o.K, ms,
+                               fl * 1e-9, by * 1e-6);
+        if (w < 0 || n + w >= cap) break;
+        n += w;
+    }
+    return n;
 }
 
 extern "C" int sd_unet_debug_tensor(sd_unet* u, void* stream, const char* name, float* host_out, long long numel,
