@@ -260,7 +260,9 @@ int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const
  * stamps per workgroup to `stamps` (caller-owned device memory, 8 * (M / 128) * slices 64-bit words) */
 /* timing ablations of the dominant kernel (the stride-1 3x3 conv with the LDS-resident halo); results are WRONG by design
  * and Y is scratch: ablate 0 = the product kernel, 1 = no LDS-DMA waits, 2 = no LDS-DMA, 4 = no tap barrier either, 8 = no
- * fragment reads either (the bare MFMA stream: the rate the matrix pipe sustains at the clock the chip holds under load) */
+ * fragment reads either (the bare MFMA stream: the rate the matrix pipe sustains at the clock the chip holds under load).
+ * + 256 (with 0 or 8): the 4-wave layout of the kernel -- 128 x 80 outputs per wave, one wave per SIMD; with 0 it is a
+ * CORRECT kernel, bit-identical to the product layout, measured 12 % slower (profiles/round3_notes.md) and kept for A/B */
 int sd_op_conv3x3_ablate(void* stream, const void* X, const void* W, void* Y, int B, int Hin, int Win, int Cin, int Cout,
                          int ablate);
 int sd_op_xattn_fused_stamps(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,

@@ -106,13 +106,14 @@ __device__ __forceinline__ float row_shr_add(float v) {      // v[i] += v[i - SH
 }
 template <int TN, int TM>
 __device__ __forceinline__ void tile_channel_stats(const f32x4 (&acc)[TN][TM], float* __restrict__ stats, long block64, int C,
-                                                   int n_base, int N, int m_base, int M, int lane) {
+                                                   int n_base, int N, int m_base, int M, int lane, int b0 = 0, int nb = TM) {
     const int lrow = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
+            if (b < b0 || b >= b0 + nb) continue;            // (pixel tiles b0 .. b0 + nb - 1: the rows of this 64-row block)
             const bool live = m_base + b * 16 + lrow < M;
             const unsigned p0 = pack2bf(acc[a][b][0], acc[a][b][1]), p1 = pack2bf(acc[a][b][2], acc[a][b][3]);
             const float v[4] = {bflo(p0), bfhi(p0), bflo(p1), bfhi(p1)};

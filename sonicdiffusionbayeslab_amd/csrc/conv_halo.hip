@@ -31,12 +31,13 @@
 namespace {
 
 constexpr int BM = 256, BN = 160;
-constexpr int TM = 4, TN = 5;                 // 16x16 tiles per wave: 64 pixels x 80 channels
-constexpr int WTM = 64, WTN = 80;
-constexpr int HSLOTS = 400;                   // 50 one-KiB DMA pieces; every wave issues 7 (6 of the 56 are re-issues)
-constexpr int HPIECES = 7;
+constexpr int TN = 5, WTN = 80;               // 16x16 tiles per wave along the channels: 80 channels
+// NWV waves per workgroup: 8 = 4 along pixels x 2 along channels, a wave owns 64 pixels x 80 channels (TM = 4), two waves
+// per SIMD; 4 = 2 x 2, 128 pixels x 80 channels (TM = 8), one wave per SIMD with up to 512 registers: 13 instead of 18
+// fragment reads per 40 MFMAs (see the kernel).
+constexpr int HSLOTS = 400;                   // 50 one-KiB DMA pieces; a wave issues 7 (8 waves) or 13 (4 waves) -- 6 / 2 re-issues
 constexpr int HBYTES = HSLOTS * 128;
-constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage; every wave issues 3 (4 re-issues)
+constexpr int WPIECES = BN / 8;               // 20 one-KiB pieces per W stage; a wave issues 3 (8 waves, 4 re-issues) or 5
 constexpr int WBYTES = WPIECES * 1024;
 constexpr int WSTAGES = 3;                    // W(kt+1) may still be in flight while tile kt is multiplied
 constexpr int SMEM = 2 * HBYTES + WSTAGES * WBYTES;   // = 160 KiB exactly
@@ -53,8 +54,22 @@ __device__ __forceinline__ int swz_of(int row, int dt) { return dt ? (((row >> 1
 // DIAG (timing ablations, WRONG results by design; SD_GEMM_TUNE bits 1 / 2 / 4, tools/conv_ab.py): 1 = the K loop never waits
 // for its LDS-DMA (vmcnt), 2 = it issues no LDS-DMA at all, 4 = no tap barrier either -- what is left of the tap time says
 // whether DMA latency, DMA issue or barrier skew parks the waves; 8 = no fragment reads either (the bare MFMA stream).
-template <int DT, int DIAG = 0>
-__global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
+//
+// NWV = 4 (bf16 only).  With 64 x 80 per wave a tap is 2 x 9 KiB of fragment reads per wave for 40 MFMAs: 8 waves read
+// 144 KiB per tap and the LDS-DMA adds 26 KiB -- 1360 LDS cycles at 128 B/clk against 1280 cycles of MFMAs per SIMD, so the
+// LDS co-limits the matrix pipe.  128 x 80 per wave needs 2 x 13 KiB for 80 MFMAs: 104 + 26 KiB = 1016 LDS cycles per tap.
+// One wave per SIMD has no partner to hide the barrier and the first fragment reads of a tap, so the second k-step's
+// MFMAs of a tap are issued after the NEXT tap's barrier from fragments carried in registers (same per-accumulator order
+// as the plain loop: bit-identical).
+template <int DT, int DIAG = 0, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(const GemmArgs p) {
+    static_assert(NWV == 8 || (NWV == 4 && DT == 0), "4-wave layout: bf16 only");
+    constexpr int NT = NWV * 64;
+    constexpr int WMW = NWV == 8 ? 4 : 2;         // waves along the pixels
+    constexpr int TM = BM / WMW / 16, WTM = TM * 16;
+    constexpr int HPIECES = NWV == 8 ? 7 : 13;    // halo DMA pieces per wave and slice
+    constexpr int WPW = NWV == 8 ? 3 : 5;         // W DMA pieces per wave and stage
+    constexpr bool CARRY = NWV == 4;
     constexpr int ESZ = DT ? 1 : 2;               // bytes per operand element; a slice = 128 / ESZ channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -102,10 +117,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     // The 50 halo pieces do not divide over 8 waves x 7: waves >= 2 re-issue their piece 5 as piece 6 (same source,
     // same LDS destination -- harmless), so that every wave issues the same number of DMAs and the counted
     // vmcnt waits of the K loop are compile-time constants.
-    const int jdup = wave < 2 ? 6 : 5;
+    const int jdup = wave < 2 ? HPIECES - 1 : HPIECES - 2;      // (50 pieces = 6 x 8 + 2 = 12 x 4 + 2)
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) {
-        const int L = (j == 6 ? jdup : j) * 512 + tid;
+        const int L = (j == HPIECES - 1 ? jdup : j) * NT + tid;
         const int slot = L >> 3, cpos = L & 7;
         const int i = slot / PP, rem = slot - i * PP;
         const int hy = rem / PW, hx = rem - hy * PW;
@@ -116,12 +131,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     }
 
     // W stage pieces: wave w issues pieces w, w + 8 and w + 16; waves 4-7 have no third piece and re-issue w + 8
-    auto wpiece = [&](int i) { return i < 2 ? wave + 8 * i : (wave < 4 ? wave + 16 : wave + 8); };
+    auto wpiece = [&](int i) { return NWV == 4 ? wave + 4 * i : (i < 2 ? wave + 8 * i : (wave < 4 ? wave + 16 : wave + 8)); };
 
     // ---- per-item state: tile origin, K range, source offsets -------------------------------------------
     int split = 0, m0 = 0, n0 = 0, s_begin = 0, s_end = 0;
     unsigned hoff[HPIECES];                      // byte offsets into X; NOSRC = zero page
-    unsigned woffs[3];                           // byte offsets into W
+    unsigned woffs[WPW];                         // byte offsets into W
     auto setup = [&](int w) {
         split = w / ntiles;
         const int t = w - split * ntiles;
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             hoff[j] = ok ? base + (unsigned)(hrel[j] & ~15) : NOSRC;
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < WPW; ++i) {
             const int pc = wpiece(i);
             const int n = n0 + pc * 8 + (lane >> 3);
             const int c = (lane & 7) ^ swz_of(lane >> 3, DT);
@@ -150,19 +165,29 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     };
     auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch (zero page), keeps the loop branch-free
         const void* src = (hoff[j] != NOSRC && s >= 0) ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
-        glds16(src, hb + (j == 6 ? jdup : j) * 8192 + wave * 1024);
+        glds16(src, hb + ((j == HPIECES - 1 ? jdup : j) * NWV + wave) * 1024);
     };
     auto issue_w1 = [&](int i, int kk, char* wb) {   // kk = slice * 9 + tap; < 0: nothing to fetch
         const void* src = (woffs[i] != NOSRC && kk >= 0) ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
         glds16(src, wb + wpiece(i) * 1024);
     };
+    auto issue_h_tap = [&](int tap, int s, char* hb) {      // the halo pieces that go out with tap `tap` of a slice
+        if (NWV == 8) {
+            if (tap < 7) issue_h(tap, s, hb);
+        } else if (tap < 5) {
+            issue_h(2 * tap, s, hb);
+            issue_h(2 * tap + 1, s, hb);
+        } else if (tap < 8) {
+            issue_h(tap + 5, s, hb);
+        }
+    };
     auto issue_w = [&](int kk, char* wb) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) issue_w1(i, kk, wb);
+        for (int i = 0; i < WPW; ++i) issue_w1(i, kk, wb);
     };
 
     // ---- fragment addressing (the same for every item) --------------------------------------------------
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WMW, wn = wave / WMW;
     const int lrow = lane & 15, lq = lane >> 4;
     int hbase[TM], hrc[TM];                       // this lane's pixels: piece base slot (+1,+1), row << 16 | column
 #pragma unroll
@@ -176,8 +201,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
     // bf16: k-step 0 reads chunk lq ^ (row & 7), k-step 1 = ^ 64; fp8: chunks 2 lq and 2 lq + 1 (= ^ 16), each ^ f(row)
     const int wswz0 = DT ? ((2 * lq) ^ swz_of(lane, 1)) << 4 : (lq ^ (lane & 7)) << 4;
 
+    auto frag_addr = [&](int f, int tp) -> int {     // this lane's pixel of tile f at tap tp: halo slot -> byte offset
+        const int hp = hbase[f] + (((hrc[f] >> 16) + (tp / 3 - 1)) >> up) * PW + (((hrc[f] & 0xffff) + (tp % 3 - 1)) >> up);
+        return hp * 128 + (DT ? (((2 * lq) ^ swz_of(hp, 1)) << 4) : ((lq ^ (hp & 7)) << 4));
+    };
+
     f32x4 acc[TN][TM];
     bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    int xan[TM];                                  // CARRY: fragment addresses of the NEXT tap (computed under this tap's MFMAs)
+#pragma unroll
+    for (int f = 0; f < TM; ++f) xan[f] = frag_addr(f, 0);
     auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
@@ -217,6 +250,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
         for (int a = 0; a < TN; ++a)
 #pragma unroll
             for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (CARRY) {                              // nothing carried into an item's first tap: zero fragments
+#pragma unroll
+            for (int f = 0; f < TM; ++f) xf1[f] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf1[a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
 
         for (int s = s_begin; s < s_end; ++s) {
             const char* hcur = hsel ? Hb1 : Hb0;
@@ -227,7 +266,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             // it costs 14 spilled descriptors (tools/ab_halo.sh, same box, interleaved).  fp8: the 32-byte fragments leave
             // no room (73 spills, reloads inside the tap loop drain the counted vmcnt pipeline), so there the values are
             // made opaque per slice and the addresses are recomputed under the MFMAs.
-            if (DT) {
+            // 4-wave layout: 72 hoisted addresses do not fit next to 104 fragment registers in the 256 arch VGPRs either, and
+            // one wave per SIMD has the issue slots to recompute them under its 80 MFMAs per tap.
+            if (DT || NWV == 4) {
 #pragma unroll
                 for (int f = 0; f < TM; ++f) asm volatile("" : "+v"(hbase[f]), "+v"(hrc[f]));
             }
@@ -238,7 +279,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 // W(kt+1) -- may still be pending; on an item's first tile also the predecessor's epilogue stores,
                 // which were issued after this item's prologue DMA.  After the barrier every wave is done reading
                 // the W stage of tile kt-1 and the halo of slice s-1, which are refilled below.
+                // (4 waves: 13 halo pieces per wave go out two per tap at taps 0-4 and one at taps 5-7, 5 W pieces every tap:
+                // the previous tap issued 0 + 5 before tap 0, 2 + 5 before taps 1-5, 1 + 5 before taps 6-8.)
                 if (DIAG == 0) {
+                if (NWV == 8) {
                 if (tap == 0) {
                     if (s == s_begin && stores_pending) wait_vmcnt<3 + FULL_STORES>();
                     else wait_vmcnt<3>();
@@ -247,6 +291,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 } else {
                     wait_vmcnt<4>();
                 }
+                } else {
+                if (tap == 0) {
+                    if (s == s_begin && stores_pending) wait_vmcnt<5 + FULL_STORES>();
+                    else wait_vmcnt<5>();
+                } else if (tap <= 5) {
+                    wait_vmcnt<7>();
+                } else {
+                    wait_vmcnt<6>();
+                }
+                }
                 }
                 if (!(DIAG & 4)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -254,17 +308,60 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                 char* wnext = Wb + (wst == 0 ? 2 : wst - 1) * WBYTES;      // stage of tile kt+2 = stage of tile kt-1
                 int xa[TM];
 #pragma unroll
-                for (int f = 0; f < TM; ++f) {
-                    const int hp = hbase[f] + (((hrc[f] >> 16) + (tap / 3 - 1)) >> up) * PW +
-                                   (((hrc[f] & 0xffff) + (tap % 3 - 1)) >> up);
-                    xa[f] = hp * 128 + (DT ? (((2 * lq) ^ swz_of(hp, 1)) << 4) : ((lq ^ (hp & 7)) << 4));
-                }
-                if (DT) {
+                for (int f = 0; f < TM; ++f) xa[f] = CARRY ? xan[f] : frag_addr(f, tap);
+                if (CARRY) {
+                    // One wave per SIMD: nothing else fills the matrix pipe while this wave issues DMAs or computes
+                    // addresses, so both are placed INSIDE the MFMA streams -- a DMA piece every 5 MFMAs of the carried
+                    // group, the next tap's fragment addresses (they do not depend on the slice) under the second group.
+                    if (!(DIAG & 8) || (tap == 0 && s == s_begin)) {        // (DIAG 8: some operand, read once per item)
+#pragma unroll
+                    for (int f = 0; f < TM; ++f) xf0[f] = *(const bf16x8*)(hcur + xa[f]);
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf0[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + wswz0);
+                    }
+                    if ((DIAG & 8) && tap == 0 && s == s_begin) {
+#pragma unroll
+                        for (int f = 0; f < TM; ++f) xf1[f] = xf0[f];
+#pragma unroll
+                        for (int a = 0; a < TN; ++a) wf1[a] = wf0[a];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int hs = more ? s + 1 : -1, kw = s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1;
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) {
+#pragma unroll
+                        for (int b = 0; b < TM; ++b) {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[a], xf1[b], acc[a][b], 0, 0, 0);
+                            const int idx = a * TM + b;
+                            if (idx % 5 == 4 && !(DIAG & 2)) {          // pieces 0..7 of this tap: 5 of W, then the halo's
+                                const int pc = idx / 5;
+                                if (pc < WPW) issue_w1(pc, kw, wnext);
+                                else if (tap < 5 && pc < WPW + 2) issue_h(2 * tap + (pc - WPW), hs, hnext);
+                                else if (tap < 8 && pc == WPW) issue_h(tap + 5, hs, hnext);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(DIAG & 8)) {
+#pragma unroll
+                    for (int f = 0; f < TM; ++f) xf1[f] = *(const bf16x8*)(hcur + (xa[f] ^ 64));
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf1[a] = *(const bf16x8*)(wcur + wfrag + a * 2048 + (wswz0 ^ 64));
+                    }
+#pragma unroll
+                    for (int f = 0; f < TM; ++f) xan[f] = frag_addr(f, tap == 8 ? 0 : tap + 1);
+                    mfmas(xf0, wf0);
+                    // the second k-step is multiplied after the next barrier: its fragments must have left the LDS before this
+                    // wave arrives there (stage and halo are refilled behind it).  The builtin, so that hipcc's wait
+                    // bookkeeping knows.
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0)
+                } else if (DT) {
 #pragma unroll
                     for (int a = 0; a < TN; ++a) wq[a] = ld32(wcur, wfrag + a * 2048 + wswz0);
                     xq[0] = ld32(hcur, xa[0]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
+                    issue_h_tap(tap, more ? s + 1 : -1, hnext);
                     issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -283,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(DIAG & 2)) {
-                    if (tap < HPIECES) issue_h(tap, more ? s + 1 : -1, hnext);
+                    issue_h_tap(tap, more ? s + 1 : -1, hnext);
                     issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -305,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             }
             hsel ^= 1;
         }
+        if (CARRY) mfmas(xf1, wf1);               // the last tap's second k-step
 
         // ---- epilogue, phase A: every LOAD the epilogue needs, folded into the accumulators now so that
         // no ordinary load is outstanding once the next item's LDS-DMA is in flight ----------------------
@@ -386,7 +484,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const GemmArgs p) {
             }
         } else {
             // GroupNorm statistics of this tile for the consuming GroupNorm (64-row blocks = this wave's rows)
-            if (p.stats) tile_channel_stats<TN, TM>(acc, p.stats, (em0 + wm * WTM) >> 6, p.N, en0 + wn * WTN, p.N, em0 + wm * WTM, p.M, lane);
+            if (p.stats) {
+#pragma unroll
+                for (int hb64 = 0; hb64 < TM / 4; ++hb64)       // one 64-row block per 4 pixel tiles
+                    tile_channel_stats<TN, TM>(acc, p.stats, ((em0 + wm * WTM) >> 6) + hb64, p.N, en0 + wn * WTN, p.N,
+                                               em0 + wm * WTM, p.M, lane, 4 * hb64, 4);
+            }
             // v_permlane16_swap pairs two adjacent 16-channel tiles: 16 contiguous bytes per lane and store
             auto store_narrow = [&](int a) {
                 const int n = en0 + wn * WTN + a * 16 + lq * 4;
@@ -485,6 +588,8 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 15, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     static const int env_tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
@@ -492,7 +597,13 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     a.tune = tune;
     int grid = a.tiles_m * a.tiles_n * a.splitk;
     if (grid > 256) grid = 256;                  // persistent: one 8-wave workgroup per CU
+    // SD_CONV_WAVES=4 or tune bit 8 (sd_op_conv3x3_ablate + 256): the 4-wave layout (128 x 80 per wave, one wave per SIMD),
+    // bf16 only.  Bit-identical to the 8-wave layout and 12 % slower at every UNet shape (round 3): kept for A/B only.
+    static const int env_waves = getenv("SD_CONV_WAVES") ? atoi(getenv("SD_CONV_WAVES")) : 8;
+    const int waves = (tune & 256) ? 4 : env_waves;
     if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
+    else if (waves == 4 && (tune & 15) == 8) hipLaunchKernelGGL((conv_halo_kernel<0, 15, 4>), dim3(grid), dim3(256), SMEM, stream, a);
+    else if (waves == 4 && (tune & 15) == 0) hipLaunchKernelGGL((conv_halo_kernel<0, 0, 4>), dim3(grid), dim3(256), SMEM, stream, a);
     else if ((tune & 15) == 1) hipLaunchKernelGGL((conv_halo_kernel<0, 1>), dim3(grid), dim3(512), SMEM, stream, a);
     else if ((tune & 15) == 2) hipLaunchKernelGGL((conv_halo_kernel<0, 3>), dim3(grid), dim3(512), SMEM, stream, a);
     else if ((tune & 15) == 4) hipLaunchKernelGGL((conv_halo_kernel<0, 7>), dim3(grid), dim3(512), SMEM, stream, a);

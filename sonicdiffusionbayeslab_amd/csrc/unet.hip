@@ -2158,7 +2158,8 @@ extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const f
 extern "C" int sd_op_conv3x3_ablate(void* stream, const void* X, const void* W, void* Y, int B, int Hin, int Win, int Cin, int Cout,
                                     int ablate) {
     if (ensure_zero_page()) return -2;
-    SD_REQUIRE(ablate == 0 || ablate == 1 || ablate == 2 || ablate == 4 || ablate == 8, "conv3x3_ablate: mode %d", ablate);
+    const int abl = ablate & ~256;               // bit 8: the 4-wave layout (128 x 80 per wave; modes 0 and 8 only)
+    SD_REQUIRE(abl == 0 || abl == 8 || (!(ablate & 256) && (abl == 1 || abl == 2 || abl == 4)), "conv3x3_ablate: mode %d", ablate);
     GemmArgs a;
     a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.C = (bf16_t*)Y; a.ldc = Cout; a.ldr = Cout;
     a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = 1; a.up = 0; a.Hout = Hin; a.Wout = Win;

@@ -146,6 +146,23 @@ def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
     assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 64, 128, 320), (3, 16, 320, 192), (5, 8, 256, 192), (1, 32, 640, 640)])
+def test_conv3x3_halo_four_wave_layout_is_bit_identical(sdlib, B, H, Cin, Cout):
+    """The A/B layout of the halo kernel (4 waves of 128 x 80 outputs, the second k-step of a tap carried over the next tap's
+    barrier; sd_op_conv3x3_ablate mode 256) issues every accumulator's MFMAs in the product kernel's order: same bits."""
+    g = torch.Generator().manual_seed(B + H + Cin)
+    xd = dev(r16(torch.randn(B, H, H, Cin, generator=g)), torch.bfloat16)
+    wd = dev(r16(torch.randn(Cout, Cin // 64, 9, 64, generator=g) / math.sqrt(9 * Cin)), torch.bfloat16)
+    outs = []
+    for mode in (0, 256):
+        out = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _lib.check(sdlib.sd_op_conv3x3_ablate(stream(), P(xd), P(wd), P(out), B, H, H, Cin, Cout, mode))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100), (5, 8, 128, 320)])
 def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
     """Upsample2D = nearest 2x + 3x3 conv, computed as four 2x2 convs on the low-res input (one per output phase) with
