@@ -733,15 +733,19 @@ static bool big_tile_ok(int M, int N, int BN) {
 // the 256 CUs and K is long enough to amortise the fp32 slab round trip.
 // Rows of the plain GEMM's output tile: 64 x 160 when 128-row tiles would leave the 512 workgroup slots (2 per CU) less
 // than 3/4 full (the 16x16 and 8x8 levels: M = 4096 / 1024), else 128 x 160.  SD_GEMM_SMALL=0: always 128.
-int sd_gemm_tile_rows(int M, int N) {
+// Not for a long K on >= 4096 rows (K = 0: unknown): 100 K tiles in ONE 64-row item lose to 128-row tiles with split-K 2
+// (the merged ff.net.2 + proj_out of the 16x16 level, 4096 x 1280 x 6400: 99.8 -> 85.4 us; every K <= 2560 shape and
+// the 1024-row level measured faster on 64 rows, tools/op_times.py with SD_GEMM_SMALL=0).
+int sd_gemm_tile_rows(int M, int N, int K) {
     static const bool off = getenv("SD_GEMM_SMALL") && atoi(getenv("SD_GEMM_SMALL")) == 0;
+    if (K >= 4096 && M >= 4096) return 128;
     return (!off && M > 64 && ((M + 127) / 128) * ((N + 159) / 160) < 384) ? 64 : 128;
 }
 
 int sd_gemm_splitk(int M, int N, int K, int rows) {
     static const char* env = getenv("SD_SPLITK");
     if (env) return atoi(env) > 1 ? atoi(env) : 1;
-    if (rows == 0) rows = sd_gemm_tile_rows(M, N);
+    if (rows == 0) rows = sd_gemm_tile_rows(M, N, K);
     const int tiles = ((M + rows - 1) / rows) * ((N + 159) / 160);
     const int KT = K / 64;
     if (tiles >= 448) return 1;           // already ~2 workgroups per CU
@@ -824,7 +828,7 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
     if (big_tile_mode() == 2) return launch<256, 160, 4, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
     // (the 64-row tile's waves own 32 rows: no GroupNorm block statistics, no LayerNorm-fold consumer on it)
-    if (!a.stats && !a.ln_rs && sd_gemm_tile_rows(a.M, a.N) == 64) return launch<64, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
+    if (!a.stats && !a.ln_rs && sd_gemm_tile_rows(a.M, a.N, a.K) == 64) return launch<64, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
     return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
 }
 

@@ -64,7 +64,7 @@ struct GemmArgs {
     float oscale = 1.0f;              // ... of out * oscale
 };
 
-int sd_gemm_tile_rows(int M, int N);        // 64 or 128: M tile of the plain (std epilogue) GEMM
+int sd_gemm_tile_rows(int M, int N, int K = 0);   // 64 or 128: M tile of the plain (std epilogue) GEMM (K = 0: not known)
 // heuristic split factor (1 = none) for the std epilogue; rows = M tile of the kernel that will run (0 = the plain bf16 GEMM's choice)
 int sd_gemm_splitk(int M, int N, int K, int rows = 0);   // heuristic split factor (1 = none) for the std epilogue
 int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu, 2 softmax over 80-column groups*/, hipStream_t stream);

@@ -1157,7 +1157,7 @@ struct Builder {
         }
         // the block's output feeds the next resnet's GroupNorm (not at the small levels: their GroupNorms are single-launch or
         // fall back to their own pass, and the statistics epilogue would keep this GEMM on 128-row tiles)
-        if (pl.ops.back().splitk == 1 && sd_gemm_tile_rows(M, C) == 128) want_stats(pl.ops.back(), M, C);
+        if (pl.ops.back().splitk == 1 && sd_gemm_tile_rows(M, C, pl.ops.back().K) == 128) want_stats(pl.ops.back(), M, C);
         return out;
     }
 
