@@ -69,6 +69,21 @@ class _VaeConfig:
 
 
 @models_registry.add_to_registry("stable_diffusion_model")
+def postprocess_images(image01: torch.Tensor, output_type: str):
+    """The tail of ``src/models.py:312-321`` (diffusers ``VaeImageProcessor.postprocess`` on denormalised images):
+    ``image01`` is ``[B, 3, H, W]`` in [0, 1].  "pt": as is; "np": float32 ``[B, H, W, 3]`` on the host; "pil": a list of
+    ``PIL.Image`` (uint8, ``round(255 x)``)."""
+    if output_type == "pt":
+        return image01
+    arr = image01.detach().to("cpu", torch.float32).permute(0, 2, 3, 1).contiguous().numpy()
+    if output_type == "np":
+        return arr
+    if output_type == "pil":
+        from PIL import Image
+        return [Image.fromarray(a) for a in (arr * 255.0).round().astype("uint8")]
+    raise NotImplementedError(f"output_type {output_type!r}")
+
+
 class StableDiffusionModel:
     vae_scale_factor = 8
 
@@ -261,14 +276,14 @@ class StableDiffusionModel:
         if output_type == "latent":
             image = latents
             image_x0 = x0_preds
-        elif output_type == "pt":
+        elif output_type in ("pt", "np", "pil"):
             vae = self._ensure_vae()
             inv = 1.0 / self.vae_config.scaling_factor
-            image = (vae.decode(latents, inv) / 2 + 0.5).clamp(0, 1)                               # :288,:312
+            image = postprocess_images((vae.decode(latents, inv) / 2 + 0.5).clamp(0, 1), output_type)   # :288,:312
             # the reference decodes EVERY stored x0 prediction as well (:296-302)
-            image_x0 = [(vae.decode(x, inv) / 2 + 0.5).clamp(0, 1) for x in x0_preds]
+            image_x0 = [postprocess_images((vae.decode(x, inv) / 2 + 0.5).clamp(0, 1), output_type) for x in x0_preds]
         else:
-            raise NotImplementedError(f"output_type {output_type!r}: 'latent' and 'pt' are built")
+            raise NotImplementedError(f"output_type {output_type!r}: 'latent', 'pt', 'np' and 'pil' are built")
         if not return_dict:
             return (image, None), execution_time, image_x0
         return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0

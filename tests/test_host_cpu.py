@@ -609,3 +609,20 @@ def test_clip_score_metric_and_its_wiring_into_validate(tmp_path, capsys):
     m2.run_experiment()
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert line["clip_score"] is None and "not computable offline" in line["clip_score_model"]
+
+
+def test_postprocess_images_np_and_pil():
+    """``output_type`` "np" / "pil" (``src/models.py:312-321``): diffusers' VaeImageProcessor.postprocess on images already
+    denormalised to [0, 1] -- NHWC float32 on the host, or uint8 PIL images rounded from 255 x."""
+    from sonicdiffusionbayeslab_amd.models import postprocess_images
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(2, 3, 8, 6, generator=g)
+    assert postprocess_images(img, "pt") is img
+    arr = postprocess_images(img, "np")
+    assert arr.shape == (2, 8, 6, 3) and arr.dtype == np.float32
+    assert np.array_equal(arr, img.permute(0, 2, 3, 1).numpy())
+    pil = postprocess_images(img, "pil")
+    assert len(pil) == 2 and pil[0].size == (6, 8) and pil[0].mode == "RGB"
+    assert np.array_equal(np.asarray(pil[1]), (arr[1] * 255.0).round().astype(np.uint8))
+    with pytest.raises(NotImplementedError):
+        postprocess_images(img, "jpeg")
