@@ -31,6 +31,19 @@
 
 namespace {
 
+// Maximum over the two lanes of a query (lane and lane ^ 32 hold different keys).  The two results of the swap are copied
+// to scalars BEFORE the bit cast: `__builtin_bit_cast(float, sw[1])` on the element of an ext-vector reads element 0 with
+// this hipcc (ROCm 7.2; `sw[0] + 2 * sw[1]` compiles to v_fmac v1, 2.0, v1), so that -- rounds 1 and 2 -- max(sw[0], sw[1])
+// was sw[0] and the running maximum the maximum over the h = 0 half's keys only.  That is still a valid softmax reference
+// (both halves used the same one), but one the other half's scores can exceed by more than the fp32 exponent range: rows
+// whose largest score sat 128 log2 units above it came out inf / NaN (test_attention_pipelined_kernel_moves_its_stale_reference).
+__device__ __forceinline__ float half_pair_max(float x) {
+    const unsigned a = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned r0 = sw[0], r1 = sw[1];
+    return fmaxf(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+}
+
 __device__ __forceinline__ int pi_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 template <int D>
@@ -175,9 +188,7 @@ __global__ __launch_bounds__(256, AttnCfg<D>::MIN_WAVES) void attn_kernel(const 
 #pragma unroll
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(s0[i], s1[i]));
         {   // max across the two half-waves (the other 16+16 keys of the same query)
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tmax),
-                                                             __builtin_bit_cast(unsigned, tmax), false, false);
-            tmax = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            tmax = half_pair_max(tmax);
         }
         const float m_new = fmaxf(m_run, tmax);
         if (!__all(m_new == m_run)) {
@@ -422,9 +433,7 @@ __global__ __launch_bounds__(DmaCfg<D>::NW * 64, D == 40 ? 4 : 3) void attn_dma_
 #pragma unroll
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(s0[i], s1[i]));
         {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tmax),
-                                                             __builtin_bit_cast(unsigned, tmax), false, false);
-            tmax = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            tmax = half_pair_max(tmax);
         }
         const float m_new = fmaxf(m_run, tmax);
         if (!__all(m_new == m_run)) {
@@ -659,9 +668,7 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         float tmax = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(s0[i], s1[i]));
-        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tmax),
-                                                         __builtin_bit_cast(unsigned, tmax), false, false);
-        return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        return half_pair_max(tmax);
     };
     auto softmax_p = [&](const f32x16& s0, const f32x16& s1, float mc, bf16x8* pf) {
 #pragma unroll
@@ -832,9 +839,7 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
         if (PING) { SD_VREADY_B(y, 0) }
         else if (ASM) { SD_VREADY_B(x, 0) }
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf[3], o[1], 0, 0, 0);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, tm0),
-                                                         __builtin_bit_cast(unsigned, tm0), false, false);
-        const float tmx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        const float tmx = half_pair_max(tm0);
         const float m_new = fmaxf(m_run, tmx);
         __builtin_amdgcn_sched_barrier(0);
         if (V & 2) {

@@ -351,6 +351,32 @@ def test_attention(sdlib, B, heads, Nq, Nk, D, spike):
     assert rel_l2(out, ref) < 1e-2   # P is rounded to bf16 before PV
 
 
+@pytest.mark.parametrize("Nk,spikes", [(512, ((70, 6.0), (300, 14.0), (509, 40.0))), (1024, ((5, 30.0), (640, 3.0))),
+                                       (256, ((250, 25.0),))])
+def test_attention_pipelined_kernel_moves_its_stale_reference(sdlib, Nk, spikes):
+    """The 64x64-level kernel (d = 40, key count a multiple of 64) keeps a STALE softmax reference M inside the QK^T product
+    and only moves it when a tile's scores exceed it by 2^8: keys scaled up mid-sequence, in the second tile and in the last
+    one force that path (and the O rescale) several times per query, with jumps from a few to hundreds of log2 units."""
+    g = torch.Generator().manual_seed(Nk)
+    B, heads, D, Nq = 1, 8, 40, 256
+    C = heads * D
+    q = r16(torch.randn(B, Nq, C, generator=g))
+    k = r16(torch.randn(B, Nk, C, generator=g))
+    v = r16(torch.randn(B, Nk, C, generator=g))
+    for pos, f in spikes:
+        k[:, pos] = r16(k[:, pos] * f)
+    qh, kh, vh = (t.view(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, C)
+    kv = dev(torch.cat([k, v], dim=-1).contiguous(), torch.bfloat16)
+    out = torch.full((B, Nq, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    kvp = P(kv)
+    _lib.check(sdlib.sd_op_attention(stream(), P(dev(q, torch.bfloat16)), C, kvp, 2 * C, kvp + 2 * C, 2 * C, P(out), C, B,
+                                     heads, Nq, Nk, D, 1.0 / math.sqrt(D)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < 1e-2
+
+
 def test_qkv_projection_and_attention_head_major(sdlib):
     """The 64x64 level's pair: the q|k|v projection stores K and V head-major ([which][sample][head][token][40]) and the
     self-attention reads them as contiguous 5 KiB tiles; against linear + scaled_dot_product_attention."""
