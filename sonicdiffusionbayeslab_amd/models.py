@@ -68,7 +68,6 @@ class _VaeConfig:
     scaling_factor = 0.18215
 
 
-@models_registry.add_to_registry("stable_diffusion_model")
 def postprocess_images(image01: torch.Tensor, output_type: str):
     """The tail of ``src/models.py:312-321`` (diffusers ``VaeImageProcessor.postprocess`` on denormalised images):
     ``image01`` is ``[B, 3, H, W]`` in [0, 1].  "pt": as is; "np": float32 ``[B, H, W, 3]`` on the host; "pil": a list of
@@ -84,6 +83,7 @@ def postprocess_images(image01: torch.Tensor, output_type: str):
     raise NotImplementedError(f"output_type {output_type!r}")
 
 
+@models_registry.add_to_registry("stable_diffusion_model")
 class StableDiffusionModel:
     vae_scale_factor = 8
 

@@ -626,3 +626,16 @@ def test_postprocess_images_np_and_pil():
     assert np.array_equal(np.asarray(pil[1]), (arr[1] * 255.0).round().astype(np.uint8))
     with pytest.raises(NotImplementedError):
         postprocess_images(img, "jpeg")
+
+
+def test_model_registry_entries_are_the_pipeline_classes():
+    """``models_registry[name].from_pretrained(...)`` is how the harness builds its model (``src/experiments/base_experiment.py:55-66``):
+    every name the reference registers (``src/models.py:21,340,628,1048``) maps to a class with that constructor."""
+    from sonicdiffusionbayeslab_amd import models
+    from sonicdiffusionbayeslab_amd.registry import models_registry
+    want = {"stable_diffusion_model": models.StableDiffusionModel,
+            "stable_diffusion_model_two_schedulers": models.StableDiffusionModelTwoSchedulers,
+            "stable_diffusion_model_interliving_schedulers": models.StableDiffusionModelInterlivingSchedulers,
+            "stable_diffusion_model_skip_timesteps": models.StableDiffusionModelSkipTimesteps}
+    for name, cls in want.items():
+        assert models_registry[name] is cls and isinstance(cls, type) and callable(getattr(cls, "from_pretrained"))
