@@ -224,8 +224,13 @@ def test_prompt_strings_and_harness_call_shape(env):
     again = model(["a man on a snowboard is coming down a slope", "People swim in the ocean"],
                   num_inference_steps=2, guidance_scale=7.5, generator=g2, output_type="latent")[0]
     assert torch.equal(imgs.images, again.images)        # deterministic: same seed, same kernels
+    # "pil" / "np" (the reference's default is "pil", src/models.py:312-321): decoded, denormalised, post-processed on the host
+    pil = model(["x"], num_inference_steps=1, output_type="pil")[0].images
+    assert len(pil) == 1 and pil[0].size == (128, 128) and pil[0].mode == "RGB"
+    arr = model(["x"], num_inference_steps=1, output_type="np")[0].images
+    assert arr.shape == (1, 128, 128, 3) and arr.min() >= 0.0 and arr.max() <= 1.0
     with pytest.raises(NotImplementedError):
-        model(["x"], num_inference_steps=1, output_type="pil")
+        model(["x"], num_inference_steps=1, output_type="jpeg")
 
 
 @pytest.mark.parametrize("name,runs", [("ddim_config.yaml", 8), ("dpm_solver_config.yaml", 7),
