@@ -26,6 +26,8 @@ DESIGN.md 2):
       7.5, compounding over the trajectory), rel-L2 <= DRIFT_TOL_10 = 6e-2 and cosine >= 0.995 after 10 steps at 64x64.
       The full 50 of 50 steps at 64x64 are an opt-in test (SD_LONG_PARITY=1, ~5 min of oracle time): last run rel-L2
       1.02e-2 / 1.03e-2 / 1.03e-2 / 1.03e-2 / 1.03e-2 after 10 / 20 / 30 / 40 / 50 steps, cosine 0.99995 throughout.
+      Same switch: the full loops of configs[2..4] at 64x64 through StableDiffusionModel.__call__ (DPM-Solver++ 20 steps
+      1.6e-2, LCM 4 steps 5.4e-3, DeepCache N = 3 over 50 steps 1.7e-2; asserted <= DRIFT_TOL_50, cosine >= 0.99).
   (d) VAE decoder 64 -> 512 (src/models.py:287-302), batch 1, vs oracle/vae.py: rel-L2 <= 2e-2, cosine >= 0.999 -- the
       128^2 .. 512^2 levels run the implicit-GEMM conv kernel the 16 -> 128 test never reaches.
 Reference call sites: src/models.py:210-282,287-302; configs/consistency_model_config.yaml:1-34."""
@@ -212,6 +214,56 @@ def test_free_running_50_of_50_ddim_steps_at_64x64(full_bf16):
                   f"rel-L2 {rel_l2(got, ref):.3e} cosine {cosine(got, ref):.5f}")
     got, ref = x.float().cpu(), traj["latents"][-1]
     assert rel_l2(got, ref) < DRIFT_TOL_50 and cosine(got, ref) > 0.99
+
+
+@pytest.mark.skipif(os.environ.get("SD_LONG_PARITY") != "1", reason="~5 min of fp32 CPU oracle; run with SD_LONG_PARITY=1")
+@pytest.mark.parametrize("which", ["dpm_solver_pp_20", "lcm_4", "deepcache_n3_50"])
+def test_other_configs_full_loops_at_64x64(full_bf16, which):
+    """BASELINE configs[2..4] at the benchmark's resolution and FULL length, through the product pipeline
+    (StableDiffusionModel.__call__ -> libsdhip) against the oracle's loop from the same latents: DPM-Solver++ (order 2)
+    20 steps with CFG 7.5; LCM 4 steps without CFG (pre-drawn re-noising tensors); DeepCache N = 3, branch 0, over 50 DDIM
+    steps with CFG 7.5.  Opt-in; the figures of the last run are in profiles/round3_notes.md."""
+    from oracle.pipeline import sample_loop
+    from oracle.schedulers import DDIMOracle, DPMSolverOracle, LCMOracle
+    from oracle.unet import DeepCacheState
+    from sonicdiffusionbayeslab_amd.deepcache import DeepCacheSDHelper
+    from sonicdiffusionbayeslab_amd.models import StableDiffusionModel
+    from sonicdiffusionbayeslab_amd.registry import schedulers_registry
+    from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
+    cfg, sd, _ = full_bf16
+    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd)).to("cuda:0")
+    stub = PNDMConfigStub().config
+    if which == "dpm_solver_pp_20":
+        kw = dict(solver_order=2, algorithm_type="dpmsolver++", final_sigmas_type="zero")
+        model.scheduler = schedulers_registry["dpm_solver_scheduler"].from_config(stub, **kw)
+        lat, pe, ne = synth_inputs(cfg, 1, seed=31)
+        out, _, _ = model(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, num_inference_steps=20, guidance_scale=7.5,
+                          output_type="latent")
+        ref = sample_loop(sd, oracle_cfg(cfg), DPMSolverOracle(**kw), pe, ne, lat, 20, 7.5)[0]
+    elif which == "lcm_4":
+        model.scheduler = schedulers_registry["lcm_scheduler"].from_config(stub)
+        lat, pe, ne = synth_inputs(cfg, 2, seed=33)
+        noise = torch.randn(3, 2, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(8))
+        out, _, _ = model(prompt_embeds=pe, latents=lat, num_inference_steps=4, guidance_scale=0.0, output_type="latent",
+                          step_noise=noise.cuda())
+        ref = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise)[0]
+    else:
+        model.scheduler = schedulers_registry["ddim_scheduler"].from_config(stub)
+        lat, pe, ne = synth_inputs(cfg, 1, seed=41)
+        helper = DeepCacheSDHelper(pipe=model)
+        helper.set_params(cache_interval=3, cache_branch_id=0)
+        helper.enable()
+        try:
+            out, _, _ = model(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, num_inference_steps=50,
+                              guidance_scale=7.5, output_type="latent")
+        finally:
+            helper.disable()
+        dc = DeepCacheState(cache_interval=3, cache_branch_id=0, enabled=True)
+        ref = sample_loop(sd, oracle_cfg(cfg), DDIMOracle(), pe, ne, lat, 50, 7.5, deepcache=dc)[0]
+    got = out.images.float().cpu()
+    err, cs = rel_l2(got, ref), cosine(got, ref)
+    print(f"{which} at 64x64, full loop: max-abs {(got - ref).abs().max().item():.3e} rel-L2 {err:.3e} cosine {cs:.5f}")
+    assert err < DRIFT_TOL_50 and cs > 0.99
 
 
 def test_vae_decode_64_to_512_matches_oracle():
