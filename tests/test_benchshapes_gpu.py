@@ -217,7 +217,7 @@ def test_free_running_50_of_50_ddim_steps_at_64x64(full_bf16):
 
 
 @pytest.mark.skipif(os.environ.get("SD_LONG_PARITY") != "1", reason="~5 min of fp32 CPU oracle; run with SD_LONG_PARITY=1")
-@pytest.mark.parametrize("which", ["dpm_solver_pp_20", "lcm_4", "deepcache_n3_50"])
+@pytest.mark.parametrize("which", ["dpm_solver_pp_20", "lcm_4", "lcm_4_fp8", "deepcache_n3_50"])
 def test_other_configs_full_loops_at_64x64(full_bf16, which):
     """BASELINE configs[2..4] at the benchmark's resolution and FULL length, through the product pipeline
     (StableDiffusionModel.__call__ -> libsdhip) against the oracle's loop from the same latents: DPM-Solver++ (order 2)
@@ -231,8 +231,27 @@ def test_other_configs_full_loops_at_64x64(full_bf16, which):
     from sonicdiffusionbayeslab_amd.registry import schedulers_registry
     from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
     cfg, sd, _ = full_bf16
-    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd)).to("cuda:0")
     stub = PNDMConfigStub().config
+    if which == "lcm_4_fp8":
+        # configs[4] with fp8-e4m3 weights + activations: against the oracle EMULATING the scheme with the per-tensor
+        # scales the pipeline calibrated on this call (and, printed, against the unquantised oracle)
+        from oracle.fp8 import Fp8Emulation
+        model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd), weight_dtype="fp8").to("cuda:0")
+        model.scheduler = schedulers_registry["lcm_scheduler"].from_config(stub)
+        lat, pe, ne = synth_inputs(cfg, 2, seed=33)
+        noise = torch.randn(3, 2, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(8))
+        out, _, _ = model(prompt_embeds=pe, latents=lat, num_inference_steps=4, guidance_scale=0.0, output_type="latent",
+                          step_noise=noise.cuda())
+        scales = {k: v for k, v in model.unet.fp8_scales().items()}
+        ref = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise, fq=Fp8Emulation(sd, scales=scales))[0]
+        plain = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise)[0]
+        got = out.images.float().cpu()
+        err, cs = rel_l2(got, ref), cosine(got, ref)
+        print(f"{which} at 64x64, full loop: vs emulating oracle rel-L2 {err:.3e} cosine {cs:.5f}; vs unquantised oracle "
+              f"{rel_l2(got, plain):.3e}; emulated scheme vs unquantised {rel_l2(ref, plain):.3e}")
+        assert err < DRIFT_TOL_50 and cs > 0.99
+        return
+    model = StableDiffusionModel(unet_config=cfg, state_dict=dict(sd)).to("cuda:0")
     if which == "dpm_solver_pp_20":
         kw = dict(solver_order=2, algorithm_type="dpmsolver++", final_sigmas_type="zero")
         model.scheduler = schedulers_registry["dpm_solver_scheduler"].from_config(stub, **kw)
