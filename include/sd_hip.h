@@ -228,6 +228,9 @@ int sd_op_gemm_qkv_headmajor(void* stream, const void* X, long long ldx, const v
                              int tokens, int K);   /* the producer: Q [M][C], KV [2][M/tokens][C/40][tokens][40] */
 int sd_op_attention_headmajor(void* stream, const void* Q, long long ldq, const void* K, const void* V, void* O,
                               long long ldo, int B, int heads, int Nq, int Nk, int D, float scale);
+/* causal self-attention of the CLIP text tower (transformers CLIPAttention, reached from src/models.py:139-155) on the fused
+ * projection output qkv [B * L][3 H] (q | k | v, bf16) -> out [B * L][H]; L <= 128, head dim 64 (16 in the reduced tests) */
+int sd_op_clip_attention(void* stream, const void* qkv, void* out, int B, int L, int H, int heads);
 int sd_op_conv_in(void* stream, const float* x, int Bsrc, const float* Wt, const float* bias, void* y, int B, int H,
                   int W, int Cin, int Cout);
 int sd_op_conv_out(void* stream, const void* x, const void* Wp, const float* bias, float* y, int B, int H, int W,
@@ -252,6 +255,14 @@ int sd_op_gemm_rowstats(void* stream, const void* X, long long ldx, const void* 
                         long long ldr, void* C, long long ldc, int M, int N, int K, float* rowstats);
 int sd_op_gemm_ln(void* stream, const void* X, long long ldx, const void* Wg, const float* c1, const float* c2,
                   const float* rowstats, int parts, float eps, void* C, long long ldc, int M, int N, int K, int epi);
+/* the std-epilogue GEMM with every side input / output the UNet plan combines on it (second K segment, bias + bias2, residual,
+ * LayerNorm row partials [2 N/160][M][2] and GroupNorm block statistics [M/64][N][2] of the stored output, the LayerNorm
+ * fold, head-major K / V) -- the entry through which tests compare the lean projection kernel (csrc/gemm_lean.hip) with
+ * the general one bit for bit (environment SD_GEMM_LEAN=0 selects the general kernel; results are identical) */
+int sd_op_gemm_plan(void* stream, const void* X, long long ldx, const void* X2, long long ldx2, int K1, const void* W,
+                    const float* bias, const float* bias2, const void* R, long long ldr, void* C, long long ldc, int M, int N,
+                    int K, float* rowstats, float* stats, const float* ln_rs, int ln_parts, const float* ln_c1, float ln_eps,
+                    void* KV, int hm_tokens);
 int sd_op_xattn_fused_rowstats(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                                const float* bias, int M, int C, int rows_per_sample, int L, float* rowstats);
 int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
@@ -262,7 +273,9 @@ int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const
  * and Y is scratch: ablate 0 = the product kernel, 1 = no LDS-DMA waits, 2 = no LDS-DMA, 4 = no tap barrier either, 8 = no
  * fragment reads either (the bare MFMA stream: the rate the matrix pipe sustains at the clock the chip holds under load).
  * + 256 (with 0 or 8): the 4-wave layout of the kernel -- 128 x 80 outputs per wave, one wave per SIMD; with 0 it is a
- * CORRECT kernel, bit-identical to the product layout, measured 12 % slower (profiles/round3_notes.md) and kept for A/B */
+ * CORRECT kernel, bit-identical to the product layout, measured 12 % slower (profiles/round3_notes.md) and kept for A/B.
+ * Every mode but 0 exists ONLY in the SD_ABLATE build of these sources (libsdhip_ablate.so, a second library next to
+ * libsdhip.so): the product library carries none of the ablation kernels and returns an error for them. */
 int sd_op_conv3x3_ablate(void* stream, const void* X, const void* W, void* Y, int B, int Hin, int Win, int Cin, int Cout,
                          int ablate);
 int sd_op_xattn_fused_stamps(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,

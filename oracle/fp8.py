@@ -65,3 +65,28 @@ class Fp8Emulation:
     def act_ff(self, x, name=None):
         s = float(self.scales.get(name, self.s_ff))
         return e4m3_round(x * s) / s
+
+
+class Fp8AmaxRecorder(Fp8Emulation):
+    """Oracle-side calibration (tests/golden/make_loop_golden.py): a forward with e4m3 WEIGHTS whose activation rounding
+    points only RECORD the largest |value| of the tensor they would quantise (the activations pass unrounded, as the
+    product's calibration pass sees them under its non-saturating probe scale).  ``calibrated_scales(margin)`` applies the product's
+    rule (csrc/unet.hip::sd_unet_calibrate_fp8): the largest power of two <= 448 / (margin x amax)."""
+
+    def __init__(self, weights):
+        super().__init__(weights)
+        self.amax: Dict[str, float] = {}
+
+    def _see(self, x, name):
+        self.amax[name] = max(self.amax.get(name, 0.0), float(x.abs().max()))
+        return x
+
+    def act_norm(self, x, name=None):
+        return self._see(x, name)
+
+    def act_ff(self, x, name=None):
+        return self._see(x, name)
+
+    def calibrated_scales(self, margin: float = 2.0) -> Dict[str, float]:
+        import math
+        return {k: 2.0 ** math.floor(math.log2(E4M3_MAX / (margin * a))) for k, a in self.amax.items() if a > 0}

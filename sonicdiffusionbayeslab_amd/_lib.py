@@ -14,7 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SD_AMD_LIB", os.path.join(HERE, "lib", "libsdhip.so"))   # (SD_AMD_LIB: A/B builds of the kernels)
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "sd_hip.h"))
 
+# the SD_ABLATE build of the same sources (build.py): timing-ablation kernels that produce WRONG results by design
+# (sd_op_conv3x3_ablate's DIAG modes, SD_GEMM_TUNE) live ONLY there -- tools/, bench.py's MFMA-stream probe and one test load it
+ABLATE_LIB_PATH = os.path.join(HERE, "lib", "libsdhip_ablate.so")
+
 _lib: Optional[C.CDLL] = None
+_ablate: Optional[C.CDLL] = None
 
 
 class SdUnetConfig(C.Structure):
@@ -87,11 +92,14 @@ _SIGS = {
     "sd_op_attention": (_i, [_vp, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f]),
     "sd_op_gemm_qkv_headmajor": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i]),
     "sd_op_attention_headmajor": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f]),
+    "sd_op_clip_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "sd_op_conv_in": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "sd_op_conv_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "sd_op_time_embedding": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "sd_op_ln_partials": (_i, [_i, _i, _i]),
     "sd_op_gemm_rowstats": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _vp]),
+    "sd_op_gemm_plan": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _f,
+                            _vp, _i]),
     "sd_op_gemm_ln": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _f, _vp, _ll, _i, _i, _i, _i]),
     "sd_op_xattn_fused_rowstats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_op_xattn_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
@@ -122,9 +130,26 @@ def load() -> C.CDLL:
     return lib
 
 
-def check(rc: int, what: str = "libsdhip call") -> None:
+def load_ablate() -> C.CDLL:
+    """libsdhip_ablate.so: a SECOND, independent instance of the library built with -DSD_ABLATE (its own globals).  Never
+    used by the product path; raises if it is not built."""
+    global _ablate
+    if _ablate is not None:
+        return _ablate
+    if not os.path.exists(ABLATE_LIB_PATH):
+        raise SdHipError(f"{ABLATE_LIB_PATH} is missing: build it with `python -m sonicdiffusionbayeslab_amd.build`")
+    lib = C.CDLL(ABLATE_LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _ablate = lib
+    return lib
+
+
+def check(rc: int, what: str = "libsdhip call", lib: Optional[C.CDLL] = None) -> None:
     if rc != 0:
-        msg = load().sd_last_error()
+        msg = (lib or load()).sd_last_error()
         raise SdHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
 
 

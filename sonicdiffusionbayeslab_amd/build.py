@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsdhip.so")
-SOURCES = ["gemm_conv.hip", "conv_halo.hip", "norm.hip", "attention.hip", "xattn.hip", "small.hip", "clip.hip", "unet.hip"]
+ABLATE_LIB_PATH = os.path.join(LIB_DIR, "libsdhip_ablate.so")
+ABLATE_SOURCES = ("gemm_conv.hip", "conv_halo.hip")     # the translation units with SD_ABLATE code
+SOURCES = ["gemm_conv.hip", "gemm_lean.hip", "conv_halo.hip", "norm.hip", "attention.hip", "xattn.hip", "small.hip", "clip.hip", "unet.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "sd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # attention is VALU-bound: keep MFMA results in arch VGPRs (no v_accvgpr_read/write copies)
@@ -52,10 +54,26 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
+    # libsdhip_ablate.so: the same library with the timing-ablation kernels compiled in (-DSD_ABLATE: DIAG instantiations
+    # of conv_halo_kernel, the SD_GEMM_TUNE branches of gemm_kernel -- WRONG results by design).  The product library above
+    # carries none of them; tools/, bench.py's MFMA-stream probe and one test load this one (_lib.load_ablate()).
+    aobjs, ajobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if src in ABLATE_SOURCES:
+            o = os.path.join(LIB_DIR, src.replace(".hip", ".ablate.o"))
+            if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
+                ajobs.append([hipcc, *FLAGS, "-DSD_ABLATE", *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
+        else:
+            o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        aobjs.append(o)
+
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
+        list(ex.map(run, jobs + ajobs))
     if force or jobs or not os.path.exists(LIB_PATH):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
+    if force or jobs or ajobs or not os.path.exists(ABLATE_LIB_PATH):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *aobjs, "-o", ABLATE_LIB_PATH])
     return LIB_PATH
 
 

@@ -166,6 +166,19 @@ __device__ __forceinline__ void tile_row_stats(const f32x4 (&acc)[TN][TM], float
     }
 }
 
+// LayerNorm-fold arithmetic of the consuming GEMMs (GemmArgs::ln_rs), with EXPLICIT fused multiply-adds: two kernels (or
+// two instantiations of one) must not differ by the compiler's choice of contraction -- a sample's result would then
+// depend on which kernel the batch size selected (the lean and the general GEMM are bit-identical by construction).
+__device__ __forceinline__ f32x2_t ln_mean_rstd(float s, float q, float inv_k, float eps) {
+    const float mean = s * inv_k;
+    const float var = __builtin_fmaf(q, inv_k, -(mean * mean));
+    return f32x2_t{mean, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + eps)};
+}
+__device__ __forceinline__ f32x4 ln_fold(f32x4 acc, f32x4 c1, float mean, float rstd, f32x4 c2) {   // rstd (acc - mean c1) + c2
+    const f32x4 nm = {-mean, -mean, -mean, -mean}, rs = {rstd, rstd, rstd, rstd};
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(c1, nm, acc), rs, c2);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

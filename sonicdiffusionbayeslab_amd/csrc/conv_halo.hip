@@ -51,7 +51,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 __device__ __forceinline__ int swz_of(int row, int dt) { return dt ? (((row >> 1) & 1) | (row & 4)) : (row & 7); }
 
-// DIAG (timing ablations, WRONG results by design; SD_GEMM_TUNE bits 1 / 2 / 4, tools/conv_ab.py): 1 = the K loop never waits
+// DIAG (timing ablations, WRONG results by design; instantiated in the SD_ABLATE build only and reached through
+// sd_op_conv3x3_ablate, never from the environment; tools/conv_ab.py): 1 = the K loop never waits
 // for its LDS-DMA (vmcnt), 2 = it issues no LDS-DMA at all, 4 = no tap barrier either -- what is left of the tap time says
 // whether DMA latency, DMA issue or barrier skew parks the waves; 8 = no fragment reads either (the bare MFMA stream).
 //
@@ -584,21 +585,25 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+#ifdef SD_ABLATE
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 15, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+#endif
         attr_set = true;
     }
-    static const int env_tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
-    const int tune = a0.tune ? a0.tune : env_tune;       // (a0.tune: sd_op_conv3x3_ablate, bench.py's measured MFMA-stream ceiling)
-    a.tune = tune;
     int grid = a.tiles_m * a.tiles_n * a.splitk;
     if (grid > 256) grid = 256;                  // persistent: one 8-wave workgroup per CU
-    // SD_CONV_WAVES=4 or tune bit 8 (sd_op_conv3x3_ablate + 256): the 4-wave layout (128 x 80 per wave, one wave per SIMD),
-    // bf16 only.  Bit-identical to the 8-wave layout and 12 % slower at every UNet shape (round 3): kept for A/B only.
+#ifdef SD_ABLATE
+    // The SD_ABLATE build only (libsdhip_ablate.so): the DIAG instantiations (timing ablations, WRONG results by design) are
+    // reached through sd_op_conv3x3_ablate (GemmArgs::tune) alone -- never from the environment; tune bit 8 (+ 256) or
+    // SD_CONV_WAVES=4 selects the 4-wave layout (128 x 80 per wave, one wave per SIMD; bf16): bit-identical to the 8-wave
+    // layout and 12 % slower at every UNet shape (round 3).
+    const int tune = a0.tune;
+    a.tune = tune;
     static const int env_waves = getenv("SD_CONV_WAVES") ? atoi(getenv("SD_CONV_WAVES")) : 8;
     const int waves = (tune & 256) ? 4 : env_waves;
     if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
@@ -609,6 +614,12 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     else if ((tune & 15) == 4) hipLaunchKernelGGL((conv_halo_kernel<0, 7>), dim3(grid), dim3(512), SMEM, stream, a);
     else if ((tune & 15) == 8) hipLaunchKernelGGL((conv_halo_kernel<0, 15>), dim3(grid), dim3(512), SMEM, stream, a);
     else hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
+#else
+    SD_REQUIRE(a0.tune == 0, "conv3x3 (halo): this build carries no ablation kernels (load libsdhip_ablate.so)");
+    a.tune = 0;
+    if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
+    else hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
+#endif
     if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
     return 0;

@@ -26,6 +26,15 @@
 
 #include <stdlib.h>
 
+// Timing ablations (SD_GEMM_TUNE bits: 8 no stores, 16 one K tile per item, 64 narrow stores -- bits 8 and 16 give WRONG
+// results by design) exist only in the SD_ABLATE build (libsdhip_ablate.so, sonicdiffusionbayeslab_amd/build.py): the
+// product library carries neither the branches nor the environment variable.
+#ifdef SD_ABLATE
+#define SD_TUNE(p) ((p).tune)
+#else
+#define SD_TUNE(p) 0
+#endif
+
 namespace {
 
 constexpr int AMODE_GEMM = 0;
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             kt_begin = 0;
             KT = KTall;
         }
-        if (p.tune & 16) KT = 1;      // diagnostic build knob: epilogue + fixed costs only (wrong results)
+        if (SD_TUNE(p) & 16) KT = 1;      // (SD_ABLATE build only) epilogue + fixed costs only: wrong results
     };
 
     // ---- per-lane source descriptors -------------------------------------------------
@@ -418,9 +427,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             }
         }
         const float invk = 1.0f / (float)p.K;
-        const float mean = s * invk;
-        const float rstd = __builtin_amdgcn_rsqf(fmaxf(q * invk - mean * mean, 0.f) + p.ln_eps);
-        *(f32x2_t*)(lnbuf + lane * 8) = f32x2_t{mean, rstd};      // row = lane; every lane needs rows b * 16 + lrow
+        *(f32x2_t*)(lnbuf + lane * 8) = ln_mean_rstd(s, q, invk, p.ln_eps);      // row = lane; every lane needs rows b * 16 + lrow
         f32x2_t mr[TM];
 #pragma unroll
         for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + (b * 16 + lrow) * 8);
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             for (int a = 0; a < TNH; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b)
-                    if (a0 + a < TN) acc[a0 + a][b] = (acc[a0 + a][b] - cv[a] * mr[b][0]) * mr[b][1] + bv[a];
+                    if (a0 + a < TN) acc[a0 + a][b] = ln_fold(acc[a0 + a][b], cv[a], mr[b][0], mr[b][1], bv[a]);
         }
     }
     if (p.splitk == 1) {
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             primed = true;
             // phase B issues exactly EPI_STORES stores per wave iff the finished tile is full
             stores_pending = (em0 + BM <= p.M) && (en0 + BN <= p.N) && (p.ldc & 7) == 0 && p.splitk == 1 &&
-                             !(p.tune & (32 | 64 | 8)) && !p.out_fp8;   // (statistics stores come before them: only more to wait for)
+                             !(SD_TUNE(p) & (32 | 64 | 8)) && !p.out_fp8;   // (statistics stores come before them: only more to wait for)
         }
     }
 
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         // adjacent tiles so that every lane owns 16 contiguous bytes -> half the store instructions,
         // 64 contiguous bytes per row per instruction.  After the swap lane group lq holds
         // lq=0: tile a cols 0-7, lq=1: tile a+1 cols 0-7, lq=2: tile a cols 8-15, lq=3: tile a+1 cols 8-15.
-        const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64);
+        const bool wide_ok = (p.ldc & 7) == 0 && !(SD_TUNE(p) & 64);
         // destination of columns col.. of row m: C, or the head-major K / V block of this tile (GemmArgs::KV)
         const bool hm = EPI == EPI_STD && p.hm_C > 0 && en0 >= p.hm_C;            // tile-uniform
         bf16_t* hm_base = nullptr;
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                 const int m = em0 + wm * WTM + b * 16 + lrow;
                 const f32x4 v = acc[a][b];
                 u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                if (m < p.M && !(p.tune & 8)) *(u32x2*)out_ptr(m, n) = o;
+                if (m < p.M && !(SD_TUNE(p) & 8)) *(u32x2*)out_ptr(m, n) = o;
             }
         };
 #pragma unroll
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                     const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
-                    if (m < p.M && !(p.tune & 8)) *(u32x4*)out_ptr(m, col) = o;
+                    if (m < p.M && !(SD_TUNE(p) & 8)) *(u32x4*)out_ptr(m, col) = o;
                 }
             } else {
                 store_narrow(a);
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     } else {
         // GEGLU: weight rows were packed so that every 32-column group is [16 value | 16 gate];
         // two output tiles (four accumulator tiles) are paired for 16-byte stores as above
-        const bool wide_ok = (p.ldc & 7) == 0 && !(p.tune & 64) && !p.out_fp8;
+        const bool wide_ok = (p.ldc & 7) == 0 && !(SD_TUNE(p) & 64) && !p.out_fp8;
         if (p.out_fp8) {
             // fp8 output (input of ff.net.2): a lane owns 4 consecutive bytes of a row per output tile, the four lane
             // groups of a row 16 contiguous bytes
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
             for (int b = 0; b < TM; ++b) {
                 const int m = em0 + wm * WTM + b * 16 + lrow;
                 const u32x2 o = geglu_tile(a, b);
-                if (m < p.M && !(p.tune & 8)) *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
+                if (m < p.M && !(SD_TUNE(p) & 8)) *(u32x2*)(p.C + (long)m * p.ldc + no) = o;
             }
         };
 #pragma unroll
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
                     const auto s1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
                     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                     const int col = (n >> 1) + (lq & 1) * 16 + (lq >> 1) * 8;
-                    if (m < p.M && !(p.tune & 8)) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+                    if (m < p.M && !(SD_TUNE(p) & 8)) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
                 }
             } else {
                 geglu_narrow(a);
@@ -689,8 +696,12 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     a.tiles_n = (a.N + BN - 1) / BN;
     if (a.ldw == 0) a.ldw = a.K;
     if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
+#ifdef SD_ABLATE
     static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
     a.tune = tune;
+#else
+    a.tune = 0;
+#endif
     // + 512 B per wave: (mean, rstd) slots of the LayerNorm fold (2-stage bf16 kernels)
     // + (c1 | c2) of the tile's BN columns
     constexpr int smem = STAGES * (BM + BN) * 128 + (STAGES == 2 && DT == 0 ? WAVES_M * WAVES_N * 512 + 2 * BN * 4 : 0);
@@ -825,6 +836,15 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
         return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_SOFTMAX>(a, stream);
     }
     if (a.rows_per_batch) return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);   // tiles must not straddle samples
+    // the UNet's full-tile projections: the lean kernel (gemm_lean.hip; same tile and accumulation order, bit-identical
+    // results, a fraction of the per-item instructions).  SD_GEMM_LEAN=0 keeps everything on gemm_kernel (A/B).
+    // (read per call, not cached: tests/test_ops_gpu.py compares the two kernels bit for bit inside one process)
+    const char* lean_env = getenv("SD_GEMM_LEAN");
+    const bool lean_off = lean_env && atoi(lean_env) == 0;
+    if (!lean_off && big_tile_mode() == 0 && sd_gemm_lean_applicable(a, epi)) {
+        const int rows = (!a.stats && !a.ln_rs && !a.hm_C) ? sd_gemm_tile_rows(a.M, a.N, a.K) : 128;
+        return sd_launch_gemm_lean(a, rows, stream);
+    }
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
     if (big_tile_mode() == 2) return launch<256, 160, 4, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);
     // (the 64-row tile's waves own 32 rows: no GroupNorm block statistics, no LayerNorm-fold consumer on it)

@@ -1,0 +1,451 @@
+// Lean bf16 MFMA GEMM for the UNet's token-major projections (gfx950):  C[M,N] = X[M,K] . W[N,K]^T  + epilogue.
+//
+// Same tile, LDS image, swizzle and MFMA schedule as gemm_conv.hip's gemm_kernel (128 x 160 or 64 x 160, four waves, two
+// persistent workgroups per CU, 2-stage LDS ring filled by 16-byte LDS-DMA), re-built around ONE measurement of round 3
+// (profiles/round3_notes.md, "Where the GEMM group's time goes"): at K = 320 ... 1600 a work item's K loop is ~330
+// instructions, while the general kernel spent ~630 instructions on the next item's decode + per-lane source pointers and
+// ~1000 on its epilogue (64-bit address arithmetic per load / store, bounds checks, zero-page selects) -- and with two
+// waves per SIMD the vector issue port, not the matrix pipe, was what the K = 320 GEMMs ran at.  Here:
+//   * every global access is a BUFFER instruction: wave-uniform resource (SGPRs) + a per-lane 32-bit offset that is
+//     computed ONCE per kernel + a scalar offset per item / K tile / row block + an immediate.  No per-item vector
+//     address arithmetic at all; rows beyond M read zeros and their stores are dropped by the hardware's range check;
+//   * the item decode is scalar and incremental (no division per item);
+//   * full N tiles only (N % 160 == 0: every UNet projection), one store schedule, the bias / c1 / c2 vectors through
+//     LDS by LDS-DMA under the first K tile, the residual and LayerNorm partial loads under the LAST K tile;
+//   * everything the general kernel's std epilogue offers to the UNet plan: second K segment (virtual concat), bias +
+//     bias2, residual, LayerNorm fold (consumer), LayerNorm row partials and GroupNorm block statistics (producer),
+//     head-major K / V stores -- bit-identical results (same accumulation order, same rounding points).
+// Shapes it does not take (N tails, split-K, per-sample weights, fp8, GEGLU / softmax epilogues, K < 128) stay on
+// gemm_kernel; sd_launch_gemm decides (gemm_conv.hip).  Reference call site: src/models.py:227-235.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+struct LeanArgs {
+    const void* X; const void* X2; const void* W; const void* R; void* C; void* KV;
+    const float* vec0; const float* vec1;      // LN fold: c1, c2;  else: bias, bias2 (either may be null)
+    const float* ln_rs; float* rowstats; float* stats;
+    unsigned x_bytes, x2_bytes, w_bytes, r_bytes, c_bytes, kv_bytes;
+    int M, N, K, K1;
+    int ldxb, ldx2b, ldwb, ldrb, ldcb;         // row strides in BYTES
+    int tiles_m, tiles_n;
+    float ln_eps, inv_k;
+    int hm_tpc;                                // head-major K / V: 160-column tiles per C (0 = off)
+    int hm_tok_shift, hm_heads, hm_samples;    // tokens per sample = 1 << shift
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+// 16 B per lane global -> LDS; LDS destination = wave-uniform base + lane * 16; source = rsrc base + voff + soff
+__device__ __forceinline__ void dma16(rsrc_t r, void* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds_wave_base), 16, voff, soff, 0, 0);
+}
+
+// LN = true: the LayerNorm-fold consumer (q|k|v with optional head-major K / V): vec0 = c1, vec1 = c2, no residual, one K
+// segment.  LN = false: bias (+ bias2) (+ residual) (+ second K segment), optional row partials / block statistics.
+// Two instantiations instead of one kernel with every feature live: the union ran out of scalar registers (11 buffer
+// resources = 44 SGPRs) and spilled them into vector lanes.  Buffer resources only for the streams that need the range
+// check or carry most of the traffic (X, X2, W, C / KV, R); the small side tensors use scalar-base global accesses.
+template <int BM, int BN, int NP>        // NP = number of LayerNorm partials per row (4, 8, 16), 0 = the LN = false kernel
+__global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
+    constexpr bool LN = NP > 0;
+    constexpr int WAVES_M = 2, WAVES_N = 2, NW = 4;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int XI = BM / 8, WI = BN / 8;
+    static_assert(XI % NW == 0 && WI % NW == 0, "pieces split evenly over the four waves");
+    constexpr int XPW = XI / NW, WPW = WI / NW;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(TN % 2 == 1, "store schedule below: TN / 2 paired 16-byte stores + one 8-byte store per row block");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lnbuf = smem + 2 * STAGE_BYTES;                 // [4 waves][64 rows] (mean, rstd)
+    char* vecs = lnbuf + NW * 512;                        // [2][BN] fp32: vec0 | vec1 of this tile's columns
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int lrow = lane & 15, lq = lane >> 4;
+
+    // ---- persistent work order: XCD-aware (blocks with equal blockIdx % 8 walk consecutive items, n fastest) -----------
+    const int nblk = gridDim.x;
+    int work;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nwork = p.tiles_m * p.tiles_n;
+    if (work >= nwork) return;
+    int tile_m = work / p.tiles_n, tile_n = work - tile_m * p.tiles_n;      // the only divisions of the kernel
+    const int dm = nblk / p.tiles_n, dn = nblk - dm * p.tiles_n;
+
+    const rsrc_t rX = make_rsrc(p.X, p.x_bytes), rW = make_rsrc(p.W, p.w_bytes), rC = make_rsrc(p.C, p.c_bytes);
+    const rsrc_t rX2 = make_rsrc(LN ? p.X : p.X2, LN ? 0 : p.x2_bytes), rR = make_rsrc(LN ? p.X : p.R, LN ? 0 : p.r_bytes);
+    const rsrc_t rKV = make_rsrc(LN ? p.KV : p.C, LN ? p.kv_bytes : 0);
+
+    // ---- per-lane offsets, computed once ------------------------------------------------------------------------------
+    const int lrow8 = lane >> 3, gch = (lane & 7) ^ lrow8;        // LDS-DMA piece: 8 rows x 128 B, chunk swizzle on the source
+    const int vX = lrow8 * p.ldxb + gch * 16, vX2 = lrow8 * p.ldx2b + gch * 16, vW = lrow8 * p.ldwb + gch * 16;
+    const int rowl = wm * WTM + lrow;                             // this lane's row inside the tile (+ 16 b)
+    const int vR = rowl * p.ldrb + (wn * WTN + lq * 4) * 2;       // residual: 4 columns (8 B) per 16 x 16 tile
+    const int vCw = rowl * p.ldcb + (wn * WTN + (lq & 1) * 16 + (lq >> 1) * 8) * 2;    // paired tiles: 8 columns (16 B)
+    const int vCn = rowl * p.ldcb + (wn * WTN + lq * 4) * 2;                           // last (odd) tile: 4 columns
+    // head-major K / V: column cl of the tile -> (head cl / 40, channel cl % 40); an 8-column group never straddles a head
+    int vH[TN / 2 + 1] = {};
+#pragma unroll
+    for (int j = 0; LN && j <= TN / 2; ++j) {
+        const int cl = wn * WTN + (j < TN / 2 ? j * 32 + (lq & 1) * 16 + (lq >> 1) * 8 : (TN - 1) * 16 + lq * 4);
+        const int hl = (cl * 205) >> 13;
+        vH[j] = ((hl << p.hm_tok_shift) + rowl) * 80 + (cl - hl * 40) * 2;
+    }
+    const int vLn = (wm * WTM + lane) * 8;                        // LayerNorm partials: lane l owns row l of its wave's 64
+    const int vRs = rowl * 8;
+    const int vSt = (wn * WTN + lq * 4) * 8;
+    const int vVec = (wn * WTN + lane * 4) * 4;                   // lanes < WTN / 4 of the waves wm == 0
+
+    // bf16 fragments: k-step ks reads chunk (4 ks + lq) ^ (row & 7)
+    const int swz[2] = {((lq) ^ (lane & 7)) << 4, ((4 + lq) ^ (lane & 7)) << 4};
+    const int xoff = (wm * WTM + lrow) * 128;
+    const int woff = BM * 128 + (wn * WTN + lrow) * 128;
+
+    const int KT = p.K >> 6;
+    int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    auto stage = [&](int kt, int buf) {
+        char* xs = smem + buf * STAGE_BYTES;
+        char* ws = xs + BM * 128;
+        const int k0 = kt * 64;
+        if (LN || k0 < p.K1) {
+            const int so = (m0 + wave * 8) * p.ldxb + k0 * 2;
+#pragma unroll
+            for (int i = 0; i < XPW; ++i) dma16(rX, xs + (wave + i * NW) * 1024, vX, so + i * (NW * 8) * p.ldxb);
+        } else {
+            const int so = (m0 + wave * 8) * p.ldx2b + (k0 - p.K1) * 2;
+#pragma unroll
+            for (int i = 0; i < XPW; ++i) dma16(rX2, xs + (wave + i * NW) * 1024, vX2, so + i * (NW * 8) * p.ldx2b);
+        }
+        const int sw = (n0 + wave * 8) * p.ldwb + k0 * 2;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) dma16(rW, ws + (wave + i * NW) * 1024, vW, sw + i * (NW * 8) * p.ldwb);
+    };
+
+    f32x4 acc[TN][TM];
+    bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    auto load_frags = [&](const char* sb, int ks, bf16x8* xf, bf16x8* wf) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8*)(sb + woff + t * 2048 + swz[ks]);
+    };
+    auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    };
+
+    // paired 16-byte stores + one 8-byte store per row block (always: full tiles) -- the counted wait below relies on it
+    constexpr int EPI_STORES = (TN / 2 + 1) * TM;
+    int g = 0;                     // running K-tile count: LDS buffer parity
+    bool stores_pending = false;
+    stage(0, 0);
+    while (true) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- K tiles 0 .. KT - 2 ---------------------------------------------------------------------------------------
+        for (int kt = 0; kt < KT - 1; ++kt) {
+            // vmcnt counts stores too and retires in order: the first K tile of an item was issued BEFORE the previous
+            // item's stores, so a counted wait retires the DMA and leaves those stores in flight under this tile's MFMAs
+            if (kt == 0 && stores_pending) wait_vmcnt<EPI_STORES>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* sb = smem + ((g + kt) & 1) * STAGE_BYTES;
+            load_frags(sb, 0, xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(kt + 1, (g + kt + 1) & 1);
+            if (kt == 0 && wm == 0 && lane < WTN / 4) {           // bias / c1 / c2 of this wave's 80 columns -> LDS
+                glds16((const char*)p.vec0 + (long)n0 * 4 + (unsigned)vVec, vecs + wn * WTN * 4);
+                glds16((const char*)p.vec1 + (long)n0 * 4 + (unsigned)vVec, vecs + BN * 4 + wn * WTN * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(sb, 1, xf1, wf1);
+            mfmas(xf0, wf0);
+            mfmas(xf1, wf1);
+        }
+        // ---- last K tile: the epilogue's loads are issued under its MFMAs (no LDS-DMA is in flight here) ---------------
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        static_assert(!LN || WTM == 64, "LayerNorm fold: lane l owns row l of its wave's 64 rows");
+        u32x2 ep[LN ? NP : TN * TM];        // the row's LayerNorm partials, or the residual's 8-byte pieces
+        {
+            const char* sb = smem + ((g + KT - 1) & 1) * STAGE_BYTES;
+            load_frags(sb, 0, xf0, wf0);
+            load_frags(sb, 1, xf1, wf1);
+            if (LN) {
+                const char* src = (const char*)p.ln_rs + (long)m0 * 8;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) ep[i] = *(const u32x2*)((src + (long)i * p.M * 8) + (unsigned)vLn);
+            } else if (p.R) {
+                const int so = m0 * p.ldrb + n0 * 2;
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+                        ep[a * TM + b] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rR, vR + a * 32, so + b * 16 * p.ldrb, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (the epilogue's arithmetic -- and its wait for these loads -- stays below the MFMAs)
+            mfmas(xf0, wf0);
+            mfmas(xf1, wf1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        g += KT;
+
+        // ---- epilogue, phase A: fold everything that was loaded into the fp32 accumulators ------------------------------
+        f32x4 v0[TN], v1[TN];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            v0[a] = *(const f32x4*)(vecs + (wn * WTN + a * 16 + lq * 4) * 4);
+            v1[a] = *(const f32x4*)(vecs + BN * 4 + (wn * WTN + a * 16 + lq * 4) * 4);
+        }
+        if (LN) {
+            // LayerNorm fold: rstd * (acc - mean * c1[n]) + c2[n]
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                // (bit_cast of the WHOLE vector: with this hipcc a bit_cast of element [1] of an ext-vector reads element [0])
+                const f32x2_t e = __builtin_bit_cast(f32x2_t, ep[i]);
+                s += e[0];
+                q += e[1];
+            }
+            *(f32x2_t*)(lnbuf + wave * 512 + lane * 8) = ln_mean_rstd(s, q, p.inv_k, p.ln_eps);   // row = lane; lanes need rows 16 b + lrow
+            f32x2_t mr[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + wave * 512 + (b * 16 + lrow) * 8);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = ln_fold(acc[a][b], v0[a], mr[b][0], mr[b][1], v1[a]);
+        } else {
+            if (p.R) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const u32x2 r = ep[a * TM + b];
+                        acc[a][b][0] += bflo(r[0]); acc[a][b][1] += bfhi(r[0]);
+                        acc[a][b][2] += bflo(r[1]); acc[a][b][3] += bfhi(r[1]);
+                    }
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const f32x4 bv = v0[a] + v1[a];                   // (a null vector was read as zeros)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] += bv;
+            }
+        }
+
+        // ---- next item: scalar decode, first K tile in flight before this item's stores ---------------------------------
+        const int em0 = m0, en0 = n0, etile_n = tile_n;
+        work += nblk;
+        const bool more = work < nwork;
+        if (more) {
+            tile_n += dn; tile_m += dm;
+            if (tile_n >= p.tiles_n) { tile_n -= p.tiles_n; tile_m += 1; }
+            m0 = tile_m * BM; n0 = tile_n * BN;
+            // (every wave has read vecs and its lnbuf slots: the LDS reads above are waited for by their uses; the stage
+            // buffer g & 1 was last read two K tiles ago, before the last barrier)
+            stage(0, g & 1);
+            stores_pending = true;
+        }
+
+        // ---- epilogue, phase B: statistics, convert, store ---------------------------------------------------------------
+        if (!LN && WTM == 64 && p.stats) {
+            // GroupNorm block statistics of the bf16-rounded outputs: [M / 64][N][2], this wave's 64 rows = one block
+            char* dst = (char*)p.stats + ((long)((em0 + wm * WTM) >> 6) * p.N + en0) * 8 + (unsigned)vSt;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const unsigned p0 = pack2bf(acc[a][b][0], acc[a][b][1]), p1 = pack2bf(acc[a][b][2], acc[a][b][3]);
+                    const float v[4] = {bflo(p0), bfhi(p0), bflo(p1), bfhi(p1)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { sv[j] += v[j]; qv[j] = __builtin_fmaf(v[j], v[j], qv[j]); }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sv[j] = row_shr_add<8>(row_shr_add<4>(row_shr_add<2>(row_shr_add<1>(sv[j]))));
+                    qv[j] = row_shr_add<8>(row_shr_add<4>(row_shr_add<2>(row_shr_add<1>(qv[j]))));
+                }
+                if (lrow == 15) {
+                    *(f32x4*)(dst + a * 128) = f32x4{sv[0], qv[0], sv[1], qv[1]};
+                    *(f32x4*)(dst + a * 128 + 16) = f32x4{sv[2], qv[2], sv[3], qv[3]};
+                }
+            }
+        }
+        if (!LN && p.rowstats) {
+            // LayerNorm partials of the bf16-rounded outputs: [2 tiles_n][M][2], per row the (sum, sum of squares) of this
+            // N-wave's 80 columns
+            char* dst = (char*)p.rowstats + ((long)(etile_n * WAVES_N + wn) * p.M + em0) * 8 + (unsigned)vRs;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const unsigned p0 = pack2bf(acc[a][b][0], acc[a][b][1]), p1 = pack2bf(acc[a][b][2], acc[a][b][3]);
+                    const float v[4] = {bflo(p0), bfhi(p0), bflo(p1), bfhi(p1)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s += v[j]; q = __builtin_fmaf(v[j], v[j], q); }
+                }
+                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+                s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+                if (lq == 0) *(f32x2_t*)(dst + b * 16 * 8) = f32x2_t{s, q};
+            }
+        }
+        // v_permlane16_swap pairs two adjacent 16 x 16 tiles so that a lane owns 8 consecutive columns (16 B) of its row:
+        // after the swap lane group lq holds  0: tile a cols 0-7, 1: tile a+1 cols 0-7, 2: tile a cols 8-15, 3: tile a+1 cols 8-15
+        u32x4 ow[TM][TN / 2];
+        u32x2 on[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+#pragma unroll
+            for (int a = 0; a + 1 < TN; a += 2) {
+                const f32x4 vx = acc[a][b], vy = acc[a + 1][b];
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
+                ow[b][a / 2] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+            const f32x4 v = acc[TN - 1][b];
+            on[b] = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
+        if (LN && p.hm_tpc > 0 && etile_n >= p.hm_tpc) {          // tile-uniform: a K or V tile of the q|k|v projection
+            // KV[which][sample][head][token][40]: which = K or V, head0 = first of this tile's four heads
+            const int which = etile_n >= 2 * p.hm_tpc ? 1 : 0;
+            const int head0 = (etile_n - (which + 1) * p.hm_tpc) * 4;
+            const int smp = em0 >> p.hm_tok_shift, tok0 = em0 & ((1 << p.hm_tok_shift) - 1);
+            const int soC = ((((which * p.hm_samples + smp) * p.hm_heads + head0) << p.hm_tok_shift) + tok0) * 80;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+#pragma unroll
+                for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rKV, vH[j], soC + b * 16 * 80, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(on[b], rKV, vH[TN / 2], soC + b * 16 * 80, 0);
+            }
+        } else {
+            const int soC = em0 * p.ldcb + en0 * 2;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+#pragma unroll
+                for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rC, vCw + j * 64, soC + b * 16 * p.ldcb, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(on[b], rC, vCn + (TN - 1) * 32, soC + b * 16 * p.ldcb, 0);
+            }
+        }
+        if (!more) break;
+    }
+}
+
+// zeros for an absent bias vector (the kernel always fetches two vectors of N floats)
+static const float* zero_vector() {
+    static float* z = nullptr;
+    if (!z) {
+        if (hipMalloc((void**)&z, 16384 * 4) != hipSuccess) return nullptr;
+        if (hipMemset(z, 0, 16384 * 4) != hipSuccess) return nullptr;
+    }
+    return z;
+}
+
+template <int BM, int NP>
+int launch_lean(const LeanArgs& a0, hipStream_t stream) {
+    LeanArgs a = a0;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = a.N / 160;
+    constexpr int smem = 2 * (BM + 160) * 128 + 4 * 512 + 2 * 160 * 4;
+    auto kern = gemm_lean_kernel<BM, 160, NP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    int grid = a.tiles_m * a.tiles_n;
+    if (grid > 512) grid = 512;        // two workgroups per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, a);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// Shapes / features the lean kernel takes (everything else runs on gemm_conv.hip's gemm_kernel).
+bool sd_gemm_lean_applicable(const GemmArgs& a, int epi) {
+    if (epi != 0 || a.dt != 0 || a.out_fp8 || a.rows_per_batch || a.subpix || (a.splitk > 1 && a.slab)) return false;
+    if (a.N % 160 != 0 || a.N > 16384 || a.K % 64 != 0 || a.K < 128 || a.K1 % 64 != 0 || a.M < 1) return false;
+    if (a.K1 != a.K && a.X2 == nullptr) return false;
+    if ((a.ldc & 7) || (a.ldx & 7) || (a.X2 && (a.ldx2 & 7)) || (a.ldw & 7) || (a.R && (a.ldr & 3))) return false;
+    const long big = 1L << 31;
+    const long ldw = a.ldw ? a.ldw : a.K;
+    if ((long)a.M * a.ldx * 2 >= big || (long)a.M * a.ldc * 2 >= big || (long)a.N * ldw * 2 >= big) return false;
+    if (a.X2 && (long)a.M * a.ldx2 * 2 >= big) return false;
+    if (a.R && (long)a.M * a.ldr * 2 >= big) return false;
+    // producer / consumer side tensors are indexed by row: whole tiles only
+    if ((a.stats || a.rowstats || a.ln_rs || a.hm_C) && a.M % 128 != 0) return false;
+    if (a.ln_rs) {      // the LN = true instantiation: one K segment, c1 / c2, 4 / 8 / 16 partials, no producer side
+        if (a.R || a.bias2 || !a.bias || !a.ln_c1 || a.X2 || a.K1 != a.K || a.stats || a.rowstats) return false;
+        if (a.ln_np != 4 && a.ln_np != 8 && a.ln_np != 16) return false;
+    }
+    if (a.hm_C) {       // head-major K / V: on the q|k|v projection, which is a LayerNorm-fold consumer in the UNet plan
+        if (!a.ln_rs || !a.KV || a.hm_C % 160 != 0 || a.N != 3 * a.hm_C || a.hm_tok < 128 || (a.hm_tok & (a.hm_tok - 1)) ||
+            a.M % a.hm_tok != 0 || (long)a.M * a.hm_C * 4 >= big)
+            return false;
+    }
+    return true;
+}
+
+int sd_launch_gemm_lean(const GemmArgs& g, int rows, hipStream_t stream) {
+    SD_REQUIRE(sd_gemm_lean_applicable(g, 0), "gemm (lean): problem not supported (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    SD_REQUIRE(rows == 128 || (rows == 64 && !g.stats && !g.ln_rs && !g.hm_C), "gemm (lean): %d-row tile with block statistics / LayerNorm fold / head-major K|V", rows);
+    const long ldw = g.ldw ? g.ldw : g.K;
+    LeanArgs a{};
+    a.X = g.X; a.X2 = g.X2; a.W = g.W; a.R = g.R; a.C = g.C; a.KV = g.KV;
+    a.M = g.M; a.N = g.N; a.K = g.K; a.K1 = g.K1;
+    a.ldxb = (int)g.ldx * 2; a.ldx2b = (int)g.ldx2 * 2; a.ldwb = (int)ldw * 2; a.ldrb = (int)g.ldr * 2; a.ldcb = (int)g.ldc * 2;
+    // resource ranges: rows beyond M (a partial last M tile) read zeros and their stores are dropped
+    a.x_bytes = (unsigned)(((long)g.M - 1) * g.ldx * 2 + (long)g.K1 * 2);
+    a.x2_bytes = g.X2 ? (unsigned)(((long)g.M - 1) * g.ldx2 * 2 + (long)(g.K - g.K1) * 2) : 0;
+    a.w_bytes = (unsigned)(((long)g.N - 1) * ldw * 2 + (long)g.K * 2);
+    a.r_bytes = g.R ? (unsigned)(((long)g.M - 1) * g.ldr * 2 + (long)g.N * 2) : 0;
+    const int ncols = g.hm_C ? g.hm_C : g.N;          // columns that go to C
+    a.c_bytes = (unsigned)(((long)g.M - 1) * g.ldc * 2 + (long)ncols * 2);
+    a.kv_bytes = g.hm_C ? (unsigned)((long)g.M * g.hm_C * 4) : 0;
+    const float* zeros = nullptr;
+    if (!g.bias || (!g.ln_rs && !g.bias2)) {
+        zeros = zero_vector();
+        SD_REQUIRE(zeros, "gemm (lean): cannot allocate the zero vector");
+    }
+    if (g.ln_rs) {
+        a.vec0 = g.ln_c1; a.vec1 = g.bias; a.ln_rs = g.ln_rs; a.ln_eps = g.ln_eps; a.inv_k = 1.0f / (float)g.K;
+    } else {
+        a.vec0 = g.bias ? g.bias : zeros; a.vec1 = g.bias2 ? g.bias2 : zeros;
+    }
+    a.rowstats = g.rowstats; a.stats = g.stats;
+    if (g.hm_C) {
+        a.hm_tpc = g.hm_C / 160;
+        int sh = 0;
+        while ((1 << sh) < g.hm_tok) ++sh;
+        a.hm_tok_shift = sh; a.hm_heads = g.hm_C / 40; a.hm_samples = g.M / g.hm_tok;
+    }
+    if (g.ln_rs) return g.ln_np == 4 ? launch_lean<128, 4>(a, stream) : g.ln_np == 8 ? launch_lean<128, 8>(a, stream) : launch_lean<128, 16>(a, stream);
+    return rows == 64 ? launch_lean<64, 0>(a, stream) : launch_lean<128, 0>(a, stream);
+}

@@ -428,10 +428,23 @@ inline unsigned char f32_to_e4m3_host(float f) {
     return sign | (unsigned char)((biased << 3) | q);
 }
 
-// host-side packing runs over up to 8 threads (0.86 G parameters: the single-threaded pack took ~20 s)
+// host-side packing runs over up to 8 threads (0.86 G parameters: the single-threaded pack took ~20 s) -- of this RANK's
+// share of the host cores: under a launcher every rank of the node packs its own replica at the same time
+// (LOCAL_WORLD_SIZE ranks; 8 ranks x 8 threads on shared cores was round 3's start-up), SD_AMD_PACK_THREADS overrides
+static int pack_threads() {
+    static const int nt = [] {
+        if (const char* e = getenv("SD_AMD_PACK_THREADS")) return std::max(1, std::min(64, atoi(e)));
+        int ranks = 1;
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+        else if (const char* e2 = getenv("WORLD_SIZE")) ranks = std::max(1, atoi(e2));
+        const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+        return std::max(1, std::min(8, cores / ranks));
+    }();
+    return nt;
+}
 template <class F>
 static void parallel_for(long n, F&& body) {
-    const int nt = (int)std::max(1l, std::min<long>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), n));
+    const int nt = (int)std::max(1l, std::min<long>(pack_threads(), n));
     if (nt == 1) { body(0l, n); return; }
     std::vector<std::thread> th;
     const long per = (n + nt - 1) / nt;
@@ -619,7 +632,7 @@ struct Packer {
         const auto& bpo = P(p + "proj_out.bias");
         const int K4 = 4 * C, KT = 5 * C;
         std::vector<float> prod((size_t)C * K4, 0.f);
-        const int nthreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        const int nthreads = pack_threads();
         const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
         auto work = [&](int tid) {
             constexpr int NB = 8;                        // output rows per pass over W2 (C is a multiple of 8)
@@ -897,9 +910,15 @@ struct Builder {
         const size_t n = key.rfind(".weight");
         return n == std::string::npos ? key : key.substr(0, n);
     }
-    float xscale(int t) const {
+    // the first inconsistency found while building (a C-ABI library reports it as an error code, it never aborts the host
+    // process): the builder carries on with harmless values and get_plan refuses the plan
+    std::string error;
+    float xscale(int t) {
         auto it = tscale.find(t);
-        if (it == tscale.end()) { fprintf(stderr, "libsdhip: fp8 consumer of a tensor without a scale\n"); abort(); }
+        if (it == tscale.end()) {
+            if (error.empty()) error = "fp8 consumer of a tensor without a scale";
+            return 1.0f;
+        }
         return it->second;
     }
     // SD_GN_PRODUCER_STATS=0: every GroupNorm runs its own statistics pass (round-1 behaviour)
@@ -959,7 +978,10 @@ struct Builder {
     }
     size_t W(const std::string& k) {
         auto it = u->woff.find(k);
-        if (it == u->woff.end()) { fprintf(stderr, "libsdhip: missing packed weight %s\n", k.c_str()); abort(); }
+        if (it == u->woff.end()) {
+            if (error.empty()) error = "missing packed weight " + k;
+            return 0;
+        }
         return it->second;
     }
     Op& push(Op op) {
@@ -1455,6 +1477,7 @@ int get_plan(sd_unet* u, int UB, int branch, Plan** out, int rep = 1) {
         pl.rep = rep;
         Builder b{u, pl, UB, {}};
         b.build();
+        SD_REQUIRE(b.error.empty(), "unet: cannot build the plan for batch %d (cache branch %d): %s", UB, branch, b.error.c_str());
         assign_memory(u, pl);
         it = u->plans.emplace(key, std::move(pl)).first;
     }
@@ -2233,6 +2256,11 @@ extern "C" int sd_op_attention(void* stream, const void* Q, long long ldq, const
     return sd_launch_attention(a, (hipStream_t)stream);
 }
 
+// the CLIP text tower's causal self-attention on the fused projection output qkv [B * L][3 H] (q | k | v) -> out [B * L][H]
+extern "C" int sd_op_clip_attention(void* stream, const void* qkv, void* out, int B, int L, int H, int heads) {
+    return sd_launch_clip_attention((const bf16_t*)qkv, (bf16_t*)out, B, L, H, heads, (hipStream_t)stream);
+}
+
 // q|k|v projection the way the plan runs it at the 64x64 level: Q token-major [M][C], K and V head-major
 // KV[2][M / tokens][C / 40][tokens][40] (GemmArgs::KV); W = [3 C][K] rows (q | k | v)
 extern "C" int sd_op_gemm_qkv_headmajor(void* stream, const void* X, long long ldx, const void* W, void* Q, void* KV, int M,
@@ -2348,6 +2376,26 @@ extern "C" int sd_op_gemm_rowstats(void* stream, const void* X, long long ldx, c
     GemmArgs a;
     a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.bias = bias; a.R = (const bf16_t*)R; a.ldr = ldr;
     a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page; a.splitk = 1; a.rowstats = rowstats;
+    return sd_launch_gemm(a, 0, (hipStream_t)stream);
+}
+// The std-epilogue GEMM with EVERY side input / output the UNet plan combines on it (tests compare the lean kernel of
+// gemm_lean.hip against the general one bit for bit through this entry, SD_GEMM_LEAN=0|1): second K segment, bias, bias2,
+// residual, LayerNorm row partials and GroupNorm block statistics of the stored output (producer side), the LayerNorm fold
+// (consumer side: ln_rs / ln_parts / ln_c1, bias = c2) and head-major K / V (hm_tokens > 0: N = 3 C, KV[2][M / tokens][C / 40][tokens][40]).
+extern "C" int sd_op_gemm_plan(void* stream, const void* X, long long ldx, const void* X2, long long ldx2, int K1, const void* W,
+                               const float* bias, const float* bias2, const void* R, long long ldr, void* C, long long ldc,
+                               int M, int N, int K, float* rowstats, float* stats, const float* ln_rs, int ln_parts,
+                               const float* ln_c1, float ln_eps, void* KV, int hm_tokens) {
+    if (ensure_zero_page()) return -2;
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.X2 = (const bf16_t*)X2; a.ldx2 = ldx2; a.K1 = K1; a.W = (const bf16_t*)W;
+    a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = ldr; a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.zero_page = g_zero_page; a.splitk = 1; a.rowstats = rowstats; a.stats = stats;
+    a.ln_rs = ln_rs; a.ln_np = ln_parts; a.ln_c1 = ln_c1; a.ln_eps = ln_eps;
+    if (hm_tokens > 0) {
+        SD_REQUIRE(N % 3 == 0 && KV, "sd_op_gemm_plan: head-major K / V needs N = 3 C and a KV buffer");
+        a.KV = (bf16_t*)KV; a.hm_C = N / 3; a.hm_tok = hm_tokens;
+    }
     return sd_launch_gemm(a, 0, (hipStream_t)stream);
 }
 // consumer: C = epi(LayerNorm(X) W^T + b) computed from the UN-normalised X: Wg = bf16(W * gamma), c1[n] = sum_k Wg[n][k],

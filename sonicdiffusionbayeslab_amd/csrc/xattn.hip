@@ -502,7 +502,7 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<31>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    // SD_XATTN_VARIANT=0: the round-2 kernel (A/B); default 15 = all round-3 changes (measured one by one on one box, 64x64
+    // SD_XATTN_VARIANT=0: the round-2 kernel (A/B); 15 = the first four round-3 changes; default 31 = all round-3 changes (measured one by one on one box, 64x64
     // launch of the bench: 72.2 us -> bias by DMA 70.9 -> + phase-1 carried group 69.9 -> + phase 2 68.5 -> + static P 68.0)
     static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 31;
     const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);

@@ -33,7 +33,12 @@ def init_process_group(backend: str = "nccl") -> Tuple[int, int, int]:
     force = os.environ.get("SD_DIST_FORCE_INIT", "0") == "1"
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:          # (only the forced world-1 case reaches here without a launcher)
+        if "MASTER_PORT" not in os.environ:
+            if world != 1:
+                # ranks of a world > 1 job started without a launcher would each pick their own port and hang in rendezvous
+                raise RuntimeError("MASTER_PORT is not set: start the ranks with `python -m torch.distributed.run --nnodes=1 "
+                                   "--nproc-per-node N --master-addr 127.0.0.1 --master-port P ...` (or export MASTER_PORT)")
+            # the forced world-1 rehearsal without a launcher: any free port
             s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {}

@@ -149,6 +149,8 @@ class BaseMethod(ABC):
         self.metric_dict = defaultdict(list)
         for point in points:
             self.model.to(self.device)
+            if hasattr(self.model, "calibrate_fp8") and not getattr(self.model, "_fp8_calibrated", True):
+                self.model.calibrate_fp8()      # fp8 handles: an explicit set-up step on EVERY rank (also one whose shards are empty)
             images, _ = self.generate(self.test_dataset.batches(batch_size), None, batch_size,
                                       guidance_scale=guidance_scale, **call_kwargs(point))
             self.model.to("cpu")
@@ -187,4 +189,15 @@ class BaseMethod(ABC):
         print(json.dumps({"experiment": self.config.experiment_name, "run": name_images, "nfe": self.model.num_timesteps,
                           "images": n_images, "time_metric_s_per_image": t,
                           "images_per_s": (1.0 / t if t > 0 else None), "weights": self.model.weights_source,
-                          "clip_score": cs, "clip_score_model": self.clip_score_source, "n_gpus": self.world}), flush=True)
+                          "clip_score": cs, "clip_score_model": self.clip_score_source, "n_gpus": self.world,
+                          "fp8_activation_scales": self._fp8_scale_report()}), flush=True)
+
+    def _fp8_scale_report(self):
+        """The e4m3 activation scales the run used (fp8 handles; None otherwise): count, range and a digest, so that two
+        runs -- or two world sizes -- can be checked to have quantised identically."""
+        sc = getattr(self.model, "fp8_scales", None)
+        if not sc:
+            return None
+        import hashlib
+        digest = hashlib.sha256(json.dumps(sorted(sc.items())).encode()).hexdigest()[:16]
+        return {"tensors": len(sc), "min": min(sc.values()), "max": max(sc.values()), "sha256_16": digest}

@@ -110,7 +110,8 @@ class StableDiffusionModel:
         self._guidance_scale = 7.5
         self._deepcache = None          # set by DeepCacheSDHelper.enable()
         self._lora = []
-        self._fp8_calibrated = False    # fp8 handles: per-tensor activation scales are calibrated on the first call's inputs
+        self._fp8_calibrated = False    # fp8 handles: per-tensor activation scales, calibrated once on a FIXED seeded batch
+        self.fp8_scales = {}            # {tensor name: scale} in use (reported by the harness next to the results)
 
     # -- loading ---------------------------------------------------------------------------
     @classmethod
@@ -248,6 +249,8 @@ class StableDiffusionModel:
         if num_images_per_prompt != 1 or timesteps is not None or sigmas is not None:
             raise NotImplementedError("custom timesteps / num_images_per_prompt are outside the reference's use")
         self._ensure_unet()
+        if not self._fp8_calibrated:
+            self.calibrate_fp8()        # fp8 handles only; shared by the four pipelines (all enter through _begin)
         device = self.unet.device
         cfgu = self.unet_config
         height = height or cfgu.sample_size * self.vae_scale_factor
@@ -288,19 +291,46 @@ class StableDiffusionModel:
             return (image, None), execution_time, image_x0
         return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None), execution_time, image_x0
 
-    def _calibrate_fp8_once(self, latents, unet_batch, ts_host, ctx):
-        """fp8 handles (``weight_dtype="fp8"``): the per-tensor e4m3 activation scales come from the amax observed on the
-        FIRST call's own inputs at the first, middle and last timestep of its schedule (``sd_unet_calibrate_fp8``, margin 2),
-        outside the timed loop; ``SD_AMD_FP8_CALIBRATE=0`` keeps the static defaults.  The scales then stay fixed for the
-        life of the model, so repeated calls are reproducible."""
-        if self._fp8_calibrated or self.unet.weight_dtype != "fp8_e4m3" or os.environ.get("SD_AMD_FP8_CALIBRATE", "1") == "0":
-            return
-        picks = [ts_host[0], ts_host[len(ts_host) // 2], ts_host[-1]]
-        self.unet.calibrate_fp8(latents, unet_batch, [float(t) for t in dict.fromkeys(picks)], margin=2.0)
-        self.unet.set_context(ctx)
+    # fixed calibration inputs: the SAME on every rank, for every prompt order, shard size and schedule
+    FP8_CALIBRATION_SEED = 20240229
+    FP8_CALIBRATION_PROMPTS = ("", "a photograph of an astronaut riding a horse")
+    FP8_CALIBRATION_TIMESTEPS = (999.0, 499.0, 1.0)
+
+    def calibrate_fp8(self, scales=None, margin: float = 2.0):
+        """fp8 handles (``weight_dtype="fp8"``): fix the per-tensor e4m3 activation scales, ONCE and deterministically.
+        ``scales`` given (e.g. saved from an earlier run: ``model.fp8_scales``): they are loaded through
+        ``sd_unet_set_fp8_scale``.  Otherwise they come from the amax observed on a fixed calibration batch -- two latents
+        drawn from a generator seeded with ``FP8_CALIBRATION_SEED``, the text encoder's embeddings of two fixed prompts, no
+        CFG, at three fixed timesteps (``sd_unet_calibrate_fp8``, margin 2) -- so every rank of a sharded run, whatever its
+        shard, and every world size end up with the SAME scales (dist.py's invariant: an image does not depend on the
+        world size; round 3 calibrated on the first call's own inputs, which differ per rank).  Runs outside any timed
+        region; ``SD_AMD_FP8_CALIBRATE=0`` keeps the static defaults (clipping at |x| > 56 / 224)."""
+        self._ensure_unet()
+        if self.unet.weight_dtype != "fp8_e4m3":
+            self._fp8_calibrated = True
+            return {}
+        if scales is not None:
+            self.unet.set_fp8_scales(scales)
+            how = "loaded"
+        elif os.environ.get("SD_AMD_FP8_CALIBRATE", "1") == "0":
+            self._fp8_calibrated = True
+            return {}
+        else:
+            cfgu = self.unet_config
+            g = torch.Generator().manual_seed(self.FP8_CALIBRATION_SEED)
+            lat = torch.randn((2, cfgu.in_channels, cfgu.sample_size, cfgu.sample_size), generator=g)
+            ctx = self.text_encoder(list(self.FP8_CALIBRATION_PROMPTS)).to(self.unet.device, torch.float32)
+            branch = self.unet.cache_branch_id
+            self.unet.set_deepcache(-1)             # the calibration pass runs the plan without DeepCache
+            self.unet.set_context(ctx)
+            self.unet.calibrate_fp8(lat, 2, list(self.FP8_CALIBRATION_TIMESTEPS), margin=margin)
+            self.unet.set_deepcache(branch)         # (the caller sets its own context next)
+            how = "calibrated on the fixed seeded batch"
+        self.fp8_scales = dict(self.unet.fp8_scales())
         self._fp8_calibrated = True
-        if "calibrated" not in self.weights_source:
-            self.weights_source += " (per-tensor e4m3 activation scales calibrated on the first call's inputs)"
+        if "e4m3 activation scales" not in self.weights_source:
+            self.weights_source += f" (per-tensor e4m3 activation scales {how})"
+        return self.fp8_scales
 
     # -- the sampling loop (src/models.py:32-335) ----------------------------------------------
     @torch.no_grad()
@@ -325,7 +355,6 @@ class StableDiffusionModel:
         dc = self._deepcache
         self.unet.set_deepcache(dc.cache_branch_id if dc is not None else -1)
         self.unet.set_context(ctx)
-        self._calibrate_fp8_once(latents, unet_batch, ts_host, ctx)
         eps = self._eps_buffer(unet_batch, device)
         self._num_timesteps = len(ts_host)
         x0_preds = []

@@ -149,6 +149,11 @@ class HipUNet2DConditionModel:
         ``set_context`` is used; ``unet_batch`` as for ``forward_latents``).  Returns ``fp8_scales()``."""
         if self.weight_dtype != "fp8_e4m3":
             raise _lib.SdHipError("calibrate_fp8: the handle was not created with weight_dtype='fp8'")
+        if self.cache_branch_id != -1:
+            # sd_unet_calibrate_fp8 runs the plan WITHOUT DeepCache; a workspace sized and a context laid out for a cache
+            # branch's plan would be read at another plan's offsets
+            raise _lib.SdHipError("calibrate_fp8: call set_deepcache(-1) and set_context(...) first (the calibration pass runs "
+                                  "the plan without DeepCache)")
         if self._ctx_key is None or self._ctx_key[2] != unet_batch:
             raise _lib.SdHipError("set_context(encoder_hidden_states) must be called for this batch first")
         latents = latents.to(self.device, torch.float32).contiguous()

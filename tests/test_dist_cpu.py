@@ -119,16 +119,20 @@ def _harness_run(lcm, nprompts, batch=5):
     return torch.stack(images), float(m.time_metric.compute()), list(m.model.calls)
 
 
-def _harness_world2(lcm, nprompts, batch=5):
+def _harness_world(world, lcm, nprompts, batch=5):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_harness_worker, args=(r, 2, port, lcm, nprompts, batch, q)) for r in range(2)]
+    ps = [ctx.Process(target=_harness_worker, args=(r, world, port, lcm, nprompts, batch, q)) for r in range(world)]
     [p.start() for p in ps]
-    outs = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+    outs = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     return outs
+
+
+def _harness_world2(lcm, nprompts, batch=5):
+    return _harness_world(2, lcm, nprompts, batch)
 
 
 def test_generate_shards_batches_and_gathers_like_single_process():
@@ -145,3 +149,22 @@ def test_generate_shards_batches_and_gathers_like_single_process():
             assert sum(calls) + sum(outs[1 - r][2]) == nprompts
         # the slowest rank's loop time is what every rank accumulates
         assert outs[0][1] == outs[1][1] and outs[0][1] <= t1
+
+
+def test_generate_at_the_world_sizes_and_global_batches_of_baseline_configs_3_and_4():
+    """BASELINE configs[3] (global batch 64 over 4 GPUs, DDIM + DeepCache: a deterministic sampler) and configs[4] (global
+    batch 256 over 8 GPUs, LCM: a Gaussian per step from the shared generator), plus a ragged 250 over 8 (ranks 0-1 hold 32
+    images, the rest 31), through ``BaseMethod.generate`` (src/experiments/base_experiment.py:122-163) with the stub
+    pipeline: every rank ends with the single-process result bit for bit, every image computed exactly once.  World 4 and 8
+    on gloo here; RCCL at N > 1 has never run (no multi-GPU box in any round so far)."""
+    for world, lcm, nprompts, batch in ((4, False, 64, 64), (8, True, 256, 256), (8, True, 250, 250), (8, False, 5, 5)):
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        want, t1, _ = _harness_run(lcm, nprompts, batch)
+        outs = _harness_world(world, lcm, nprompts, batch)
+        assert sorted(outs) == list(range(world))
+        per_rank = [sum(outs[r][2]) for r in range(world)]
+        assert sum(per_rank) == nprompts and max(per_rank) - min(per_rank) <= 1, per_rank      # contiguous, balanced shards
+        for r in range(world):
+            assert torch.equal(outs[r][0], want), (world, lcm, nprompts, r)
+            assert outs[r][1] == outs[0][1]

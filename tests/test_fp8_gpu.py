@@ -287,7 +287,7 @@ def test_lcm_loop_fp8(small_fp8):
     out, secs, _ = model(prompt_embeds=pe, latents=lat, num_inference_steps=4, guidance_scale=0.0,
                          output_type="latent", step_noise=noise.cuda())
     assert "fp8_e4m3" in model.weights_source
-    scales = model.unet.fp8_scales(with_amax=True)       # the pipeline calibrated them on this call's inputs
+    scales = model.unet.fp8_scales(with_amax=True)       # the pipeline calibrated them on its fixed seeded batch before the loop
     assert scales and all(a > 0 for _, a in scales.values()) and "calibrated" in model.weights_source
     ref_q, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise,
                                  fq=Fp8Emulation(sd, scales={k: v[0] for k, v in scales.items()}))

@@ -149,18 +149,24 @@ def test_conv3x3(sdlib, B, H, Cin, Cout, stride, up, extras):
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 64, 128, 320), (3, 16, 320, 192), (5, 8, 256, 192), (1, 32, 640, 640)])
 def test_conv3x3_halo_four_wave_layout_is_bit_identical(sdlib, B, H, Cin, Cout):
     """The A/B layout of the halo kernel (4 waves of 128 x 80 outputs, the second k-step of a tap carried over the next tap's
-    barrier; sd_op_conv3x3_ablate mode 256) issues every accumulator's MFMAs in the product kernel's order: same bits."""
+    barrier; sd_op_conv3x3_ablate mode 256 of the SD_ABLATE build, libsdhip_ablate.so) issues every accumulator's MFMAs in
+    the product kernel's order: the same bits as the PRODUCT library's kernel.  The product library itself refuses every
+    ablation mode: it carries none of those kernels."""
+    abl = _lib.load_ablate()
     g = torch.Generator().manual_seed(B + H + Cin)
     xd = dev(r16(torch.randn(B, H, H, Cin, generator=g)), torch.bfloat16)
     wd = dev(r16(torch.randn(Cout, Cin // 64, 9, 64, generator=g) / math.sqrt(9 * Cin)), torch.bfloat16)
     outs = []
-    for mode in (0, 256):
+    for lib, mode in ((sdlib, 0), (abl, 0), (abl, 256)):
         out = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
-        _lib.check(sdlib.sd_op_conv3x3_ablate(stream(), P(xd), P(wd), P(out), B, H, H, Cin, Cout, mode))
+        _lib.check(lib.sd_op_conv3x3_ablate(stream(), P(xd), P(wd), P(out), B, H, H, Cin, Cout, mode), lib=lib)
         torch.cuda.synchronize()
         outs.append(out)
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    for mode in (8, 256):
+        assert sdlib.sd_op_conv3x3_ablate(stream(), P(xd), P(wd), P(outs[1]), B, H, H, Cin, Cout, mode) != 0
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100), (5, 8, 128, 320)])
@@ -305,6 +311,90 @@ def test_layernorm_folded_into_gemm(sdlib, M, C, N2, epi, mean):
     assert rel_l2(out, ref) < TOL
 
 
+def _gemm_plan(sdlib, lean, x, x2, w, b, b2, r, M, N, K, K1, want_rs=False, want_st=False, ln=None, hm_tokens=0):
+    """One sd_op_gemm_plan call on the lean (gemm_lean.hip) or the general (gemm_conv.hip) kernel.  Returns (C, rowstats,
+    stats, KV) -- untouched outputs stay NaN."""
+    import os
+    os.environ["SD_GEMM_LEAN"] = "1" if lean else "0"
+    try:
+        ncols = N // 3 if hm_tokens else N
+        out = torch.full((M, ncols), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rs = torch.full((2 * (N // 160), M, 2), float("nan"), device="cuda") if want_rs else None
+        st = torch.full((M // 64, N, 2), float("nan"), device="cuda") if want_st else None
+        kv = torch.full((2, M // hm_tokens, ncols // 40, hm_tokens, 40), float("nan"), device="cuda", dtype=torch.bfloat16) if hm_tokens else None
+        ln_rs, ln_parts, ln_c1 = ln if ln else (None, 0, None)
+        _lib.check(sdlib.sd_op_gemm_plan(stream(), P(x), K1, P(x2), K - K1, K1, P(w), P(b), P(b2), P(r), N, P(out), ncols, M, N, K,
+                                         P(rs), P(st), P(ln_rs), ln_parts, P(ln_c1), 1e-5, P(kv), hm_tokens))
+        torch.cuda.synchronize()
+        return out, rs, st, kv
+    finally:
+        os.environ.pop("SD_GEMM_LEAN", None)
+
+
+@pytest.mark.parametrize("M,N,K,K1,bias,bias2,res,rowstats,stats", [
+    (256, 320, 320, 320, True, False, False, False, False),
+    (384, 640, 1600, 1280, True, False, True, False, True),      # merged ff.net.2 + proj_out: two K segments, residual, block statistics
+    (256, 320, 320, 320, True, False, True, True, False),        # to_out / proj_in: residual + LayerNorm row partials
+    (130, 960, 640, 640, False, False, False, False, False),     # M tail: rows beyond M read zeros, their stores are dropped
+    (64, 1280, 2560, 1280, True, True, True, False, False),      # 64-row tiles never mix samples; bias2
+    (1000, 160, 128, 128, True, True, False, False, False),      # smallest K the lean kernel takes (two K tiles), one N tile
+])
+def test_gemm_lean_kernel_is_bit_identical_to_the_general_kernel(sdlib, M, N, K, K1, bias, bias2, res, rowstats, stats):
+    """csrc/gemm_lean.hip re-builds the std-epilogue GEMM of the UNet's projections around buffer addressing (a fraction of
+    the per-item instructions); same tile, same accumulation order, same rounding points -> the same BITS as gemm_kernel,
+    for every side input / output the plan combines (call site src/models.py:227-235).  Also vs fp32 torch."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = r16(torch.randn(M, K, generator=g))
+    w = r16(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) if bias else None
+    b2 = torch.randn(N, generator=g) if bias2 else None
+    r = r16(torch.randn(M, N, generator=g)) if res else None
+    x1 = dev(x[:, :K1].contiguous(), torch.bfloat16)
+    x2 = dev(x[:, K1:].contiguous(), torch.bfloat16) if K1 < K else None
+    args = (x1, x2, dev(w, torch.bfloat16), dev(b) if bias else None, dev(b2) if bias2 else None,
+            dev(r, torch.bfloat16) if res else None, M, N, K, K1, rowstats, stats)
+    lean, general = _gemm_plan(sdlib, True, *args), _gemm_plan(sdlib, False, *args)
+    ref = x @ w.t()
+    for t in (b, b2, r):
+        if t is not None:
+            ref = ref + t
+    assert rel_l2(lean[0], ref) < TOL
+    for a, c in zip(lean, general):
+        assert (a is None) == (c is None)
+        if a is not None:
+            assert torch.isfinite(a.float()).all() and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("B,tokens,C,mean", [(2, 4096, 320, 0.0), (1, 256, 640, 1.5), (1, 128, 1280, 0.3)])
+def test_gemm_lean_layernorm_fold_and_headmajor_kv(sdlib, B, tokens, C, mean):
+    """The q|k|v projection as the plan runs it at the 64x64 level: LayerNorm folded in (4 / 8 / 16 row partials) AND K / V
+    stored head-major, on the lean kernel -- bit-identical to the general kernel, and its head-major K / V are exactly the
+    token-major columns of the same call without the head-major option, re-ordered."""
+    M, N = B * tokens, 3 * C
+    g = torch.Generator().manual_seed(B + tokens + C)
+    h = r16(torch.randn(M, C, generator=g) * 2 + mean)
+    h[:, 3] += 9.0                                   # an outlier channel
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    wg, c1, c2 = fold_layernorm(w, gamma, beta, torch.zeros(N))
+    parts = 2 * (C // 160)
+    hh = h.view(M, parts, C // parts)
+    rs = torch.stack([hh.sum(2), (hh * hh).sum(2)], dim=2).permute(1, 0, 2).contiguous()      # [parts][M][2]
+    ln = (dev(rs), parts, dev(c1))
+    args = (dev(h, torch.bfloat16), None, dev(wg, torch.bfloat16), dev(c2), None, None, M, N, C, C)
+    plain = _gemm_plan(sdlib, True, *args, ln=ln)[0]
+    ref = F.layer_norm(h, (C,), gamma, beta, 1e-5) @ r16(w).t()
+    assert rel_l2(plain, ref) < TOL
+    assert torch.equal(plain, _gemm_plan(sdlib, False, *args, ln=ln)[0])
+    if C // 40 == 8:                                 # head dim 40, >= 8192 rows (128-row tiles): the 64x64 level's layout
+        for lean in (True, False):
+            q, _, _, kv = _gemm_plan(sdlib, lean, *args, ln=ln, hm_tokens=tokens)
+            assert torch.equal(q, plain[:, :C])
+            for which in (0, 1):
+                want = plain[:, (1 + which) * C:(2 + which) * C].reshape(B, tokens, C // 40, 40).permute(0, 2, 1, 3)
+                assert torch.equal(kv[which], want)
+
+
 @pytest.mark.parametrize("rows,C", [(300, 320), (77, 640), (1024, 1280)])
 def test_layernorm(sdlib, rows, C):
     g = torch.Generator().manual_seed(rows)
@@ -375,6 +465,73 @@ def test_attention_pipelined_kernel_moves_its_stale_reference(sdlib, Nk, spikes)
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     assert rel_l2(out, ref) < 1e-2
+
+
+def _dominant_key_case(g, B, heads, D, Nq, Nk, spikes):
+    """Queries with a common component u, keys f * u at the given positions: key `pos` then scores ~ 18 f log2 units above
+    everything before it for EVERY query (q . u = 2 D +- sqrt(D)), as the BOS key of a real prompt / an outlier channel of
+    a real checkpoint does.  Escalating factors make each spike exceed the previous maximum by >= 150 log2 units."""
+    C = heads * D
+    u = torch.ones(C)
+    q = r16(torch.randn(B, Nq, C, generator=g) + 2.0 * u)
+    k = r16(torch.randn(B, Nk, C, generator=g))
+    v = r16(torch.randn(B, Nk, C, generator=g))
+    for pos, f in spikes:
+        k[:, pos] = r16(f * u * (math.sqrt(40.0 / D)) + 0.1 * k[:, pos])     # ~ the same log2 jump per unit of f for every D
+    return q, k, v
+
+
+@pytest.mark.parametrize("D,Nk,spikes", [
+    (40, 77, ((5, 13.0), (41, 26.0), (76, 39.0))),          # attn_dma_kernel<40>: the 77-key prompt shape, both lane halves
+    (40, 200, ((9, 13.0), (68, 26.0), (197, 39.0))),        # attn_dma_kernel<40>: key count not a multiple of 64
+    (40, 512, ((13, 13.0), (300, 26.0), (509, 39.0))),      # attn_pipe40_kernel (stale reference): jumps of >= 150 log2 units
+    (80, 256, ((5, 13.0), (130, 26.0), (251, 39.0))),       # attn_kernel<80>
+    (80, 1024, ((9, 13.0), (520, 26.0), (1021, 39.0))),
+    (160, 64, ((4, 13.0), (25, 26.0), (61, 39.0))),         # attn_kernel<160>
+    (160, 256, ((12, 13.0), (100, 26.0), (255, 39.0))),
+])
+def test_attention_running_maximum_survives_dominant_keys_in_either_lane_half(sdlib, D, Nk, spikes):
+    """Rounds 1-2 shipped a running maximum that covered only HALF of the keys of a tile (the other lane of a query's lane
+    pair, csrc/attention.hip::half_pair_max): an exact softmax still, so every parity test passed, until a score in the
+    uncovered half sat > 128 log2 units above it and exp2 overflowed.  Every flash-attention kernel (d = 40 DMA / pipelined,
+    d = 80, d = 160) is driven here with dominant keys at early / middle / last positions whose index covers both values of
+    bits 2 and 3 (the accumulator rows one lane of the pair owns), each >= 150 log2 units above the maximum before it:
+    finite, and rel-L2 <= 1e-2 against fp32 SDPA (src/models.py:227-235: real prompts have a dominant BOS key)."""
+    g = torch.Generator().manual_seed(D * 1000 + Nk)
+    B, heads, Nq = 1, 8, 256
+    C = heads * D
+    q, k, v = _dominant_key_case(g, B, heads, D, Nq, Nk, spikes)
+    qh, kh, vh = (t.view(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
+    scale = 1.0 / math.sqrt(D)
+    s = (qh @ kh.transpose(-1, -2)) * scale * 1.4426950408889634
+    for pos, _ in spikes:                                          # the construction really produces the jumps it claims
+        assert (s[..., pos] - s[..., :pos].amax(-1)).min() > 150.0
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, C)
+    kv = dev(torch.cat([k, v], dim=-1).contiguous(), torch.bfloat16)
+    out = torch.full((B, Nq, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    kvp = P(kv)
+    _lib.check(sdlib.sd_op_attention(stream(), P(dev(q, torch.bfloat16)), C, kvp, 2 * C, kvp + 2 * C, 2 * C, P(out), C, B,
+                                     heads, Nq, Nk, D, scale))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < 1e-2
+
+
+def test_clip_attention_with_a_dominant_bos_key(sdlib):
+    """The CLIP text tower's causal attention (csrc/clip.hip, 77 tokens): every query sees key 0 (BOS) scoring ~700 log2
+    units above the rest, as real CLIP text models do; exact two-pass softmax -> finite and equal to fp32 SDPA."""
+    g = torch.Generator().manual_seed(77)
+    B, L, heads, D = 2, 77, 12, 64
+    H = heads * D
+    q, k, v = _dominant_key_case(g, B, heads, D, L, L, ((0, 40.0),))
+    qkv = dev(torch.cat([q, k, v], dim=-1).contiguous(), torch.bfloat16)
+    out = torch.full((B * L, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_clip_attention(stream(), P(qkv), P(out), B, L, H, heads))
+    torch.cuda.synchronize()
+    qh, kh, vh = (t.view(B, L, heads, D).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(B * L, H)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < TOL
 
 
 def test_qkv_projection_and_attention_head_major(sdlib):
@@ -525,7 +682,8 @@ def test_gemm_batched_weights_and_grouped_softmax(sdlib, B, rows, N, K, epi):
         assert (o[..., 77:] == 0).all() and (o.sum(-1) - 1).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("B,hw,C,spike", [(2, 256, 320, False), (1, 1024, 640, True), (3, 128, 1280, False), (2, 4096, 320, False)])
+@pytest.mark.parametrize("B,hw,C,spike", [(2, 256, 320, False), (1, 1024, 640, True), (3, 128, 1280, False), (2, 4096, 320, False),
+                                          (2, 256, 320, 40.0), (1, 128, 1280, 40.0)])
 def test_xattn_fused(sdlib, B, hw, C, spike):
     """Fused prompt cross-attention (xattn.hip; src/models.py:227-235 -> diffusers Attention over the 77 prompt keys):
     Y = R + to_out(softmax(to_q(X) K^T / sqrt(d)) V) + b in ONE launch with A_h = scale W_q,h^T K_h^T and
@@ -542,8 +700,14 @@ def test_xattn_fused(sdlib, B, hw, C, spike):
     wk, wv = (torch.randn(C, 768, generator=g) / math.sqrt(768) for _ in range(2))
     bo = torch.randn(C, generator=g)
     ctx = torch.randn(B, L, 768, generator=g)
-    if spike:
+    if spike is True:
         ctx[0, 5] *= 6.0                      # one dominant key: exercises the max subtraction
+    elif spike:
+        # a BOS-like key: EVERY query of every head scores it far above the other 76 (real prompts: key 0), hundreds of
+        # log2 units -- the probabilities collapse onto it and nothing may overflow on the way.  Queries share the component
+        # W_q 1 (x = noise + 1); the key is made parallel to it: K_0 = wk ctx_0 ~ c W_q 1 -> score_h ~ c sqrt(d) +- c.
+        x = r16(x + 1.0)
+        ctx[:, 0] = spike * (torch.linalg.pinv(wk) @ (wq @ torch.ones(C)))
     K, V = ctx @ wk.t(), ctx @ wv.t()         # [B, L, C]
     scale = 1.0 / math.sqrt(d)
     At = torch.zeros(B, H * 80, C)

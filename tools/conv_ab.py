@@ -1,6 +1,6 @@
 """A/B of the halo conv at the UNet's shapes: times every shape and prints a SHA-256 of the output bytes, so that two
-builds / two SD_GEMM_TUNE settings (bit 128 = round-2 K-loop order) can be compared for speed AND for bitwise identity:
-    python tools/conv_ab.py > a.txt;  SD_GEMM_TUNE=128 python tools/conv_ab.py > b.txt;  diff <(cut -f1,3 a.txt) <(cut -f1,3 b.txt)
+builds (SD_AMD_LIB=<other libsdhip.so>) can be compared for speed AND for bitwise identity:
+    python tools/conv_ab.py > a.txt;  SD_AMD_LIB=/path/to/other/libsdhip.so python tools/conv_ab.py > b.txt;  diff <(cut -f1,3 a.txt) <(cut -f1,3 b.txt)
 Development tool."""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
