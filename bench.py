@@ -223,13 +223,13 @@ PMC_SOURCE = (f"{PMC_FILE} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GU
 
 def kernel_sources_sha16():
     """Fingerprint of the kernel sources a committed PMC profile belongs to (the GPU box has no .git): sha256 over the
-    contraction kernels and their launch heuristics -- csrc/conv_halo.hip, gemm_conv.hip, xattn.hip, attention.hip, common.h,
-    kernels.h -- first 16 hex digits.  tools/pmc_*.py stamp it into the profile JSON and the readers below refuse a
+    kernels and everything that decides which of them run with what split / tile (the plan builder in unet.hip included) --
+    every file of csrc/ -- first 16 hex digits.  tools/pmc_*.py stamp it into the profile JSON and the readers below refuse a
     profile whose stamp is not the current one (a stale counter is worse than none)."""
     import hashlib
     h = hashlib.sha256()
     root = os.path.join(ROOT, "sonicdiffusionbayeslab_amd", "csrc")
-    for f in [os.path.join(root, n) for n in ("attention.hip", "common.h", "conv_halo.hip", "gemm_conv.hip", "kernels.h", "xattn.hip")]:
+    for f in [os.path.join(root, n) for n in sorted(os.listdir(root)) if n.endswith((".hip", ".h"))]:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -31,6 +31,18 @@ def _newer(a: str, b: str) -> bool:
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def check_attention_asm(path: str) -> None:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lds_waits", os.path.join(HERE, "..", "tools", "check_lds_waits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.main(path, ["attn_pipe40_kernel"]) != 0:
+        os.remove(path)
+        raise RuntimeError("attention.hip: hipcc's code around the inline-asm ds_read_b64_tr_b16 reads violates their hand-counted "
+                           "lgkmcnt waits (see the VIOLATION lines above); build with the attention kernel's variant 0 "
+                           "(SD_ATTN_VARIANT=0 uses no inline-asm reads) only after fixing the source")
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -68,8 +80,19 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
             o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         aobjs.append(o)
 
+    # attention.hip waits for its inline-asm V^T fragment reads with hand-counted `s_waitcnt lgkmcnt(N)`: the .s of the SAME
+    # flags is checked on every (re)build (tools/check_lds_waits.py: no MFMA / copy / spill touches a fragment register
+    # before its read is waited for) and a violation FAILS the build -- nothing else pins what hipcc does around them.
+    attn_s = os.path.join(LIB_DIR, "attention.s")
+    attn_src = os.path.join(CSRC, "attention.hip")
+    check_attn = force or _newer(attn_src, attn_s) or any(_newer(h, attn_s) for h in hdrs)
+    if check_attn:
+        jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS["attention.hip"], "-S", "--cuda-device-only", attn_src, "-o", attn_s])
+
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs + ajobs))
+    if check_attn:
+        check_attention_asm(attn_s)
     if force or jobs or not os.path.exists(LIB_PATH):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
     if force or jobs or ajobs or not os.path.exists(ABLATE_LIB_PATH):

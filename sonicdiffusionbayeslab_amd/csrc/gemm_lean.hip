@@ -55,20 +55,25 @@ __device__ __forceinline__ void dma16(rsrc_t r, void* lds_wave_base, int voff, i
 // Two instantiations instead of one kernel with every feature live: the union ran out of scalar registers (11 buffer
 // resources = 44 SGPRs) and spilled them into vector lanes.  Buffer resources only for the streams that need the range
 // check or carry most of the traffic (X, X2, W, C / KV, R); the small side tensors use scalar-base global accesses.
-template <int BM, int BN, int NP>        // NP = number of LayerNorm partials per row (4, 8, 16), 0 = the LN = false kernel
-__global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
+// NP = number of LayerNorm partials per row (4, 8, 16), 0 = the LN = false kernel.  GEGLU: the 256 x 256 tile on 8 waves
+// (one workgroup per CU: half the LDS-fill bytes per flop of 128 x 128), weight rows packed [16 value | 16 gate] per 32
+// columns, output N / 2 columns of value * gelu(gate); LayerNorm fold or plain bias, nothing else.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, bool GEGLU>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(const LeanArgs p) {
     constexpr bool LN = NP > 0;
-    constexpr int WAVES_M = 2, WAVES_N = 2, NW = 4;
+    constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int XI = BM / 8, WI = BN / 8;
-    static_assert(XI % NW == 0 && WI % NW == 0, "pieces split evenly over the four waves");
+    static_assert(XI % NW == 0 && WI % NW == 0, "pieces split evenly over the waves");
     constexpr int XPW = XI / NW, WPW = WI / NW;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static_assert(TN % 2 == 1, "store schedule below: TN / 2 paired 16-byte stores + one 8-byte store per row block");
+    static_assert(GEGLU ? TN % 4 == 0 : TN % 2 == 1, "store schedule: GEGLU pairs of output tiles; std TN / 2 paired + one 8-byte store");
+    constexpr bool FRAG_DB = TM * TN * 4 + (TM + TN) * 8 <= 200;     // accumulators + two fragment sets fit 256 registers
+    constexpr int TNH = GEGLU ? TN / 2 : TN;                         // bias / c1 / c2 vectors held at a time
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lnbuf = smem + 2 * STAGE_BYTES;                 // [4 waves][64 rows] (mean, rstd)
+    char* lnbuf = smem + 2 * STAGE_BYTES;                 // [waves][64 rows] (mean, rstd)
     char* vecs = lnbuf + NW * 512;                        // [2][BN] fp32: vec0 | vec1 of this tile's columns
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,10 +104,11 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
     const int vR = rowl * p.ldrb + (wn * WTN + lq * 4) * 2;       // residual: 4 columns (8 B) per 16 x 16 tile
     const int vCw = rowl * p.ldcb + (wn * WTN + (lq & 1) * 16 + (lq >> 1) * 8) * 2;    // paired tiles: 8 columns (16 B)
     const int vCn = rowl * p.ldcb + (wn * WTN + lq * 4) * 2;                           // last (odd) tile: 4 columns
+    const int vCg = rowl * p.ldcb + (wn * WTN / 2 + (lq & 1) * 16 + (lq >> 1) * 8) * 2;  // GEGLU: 8 of the N / 2 output columns
     // head-major K / V: column cl of the tile -> (head cl / 40, channel cl % 40); an 8-column group never straddles a head
     int vH[TN / 2 + 1] = {};
 #pragma unroll
-    for (int j = 0; LN && j <= TN / 2; ++j) {
+    for (int j = 0; LN && !GEGLU && j <= TN / 2; ++j) {
         const int cl = wn * WTN + (j < TN / 2 ? j * 32 + (lq & 1) * 16 + (lq >> 1) * 8 : (TN - 1) * 16 + lq * 4);
         const int hl = (cl * 205) >> 13;
         vH[j] = ((hl << p.hm_tok_shift) + rowl) * 80 + (cl - hl * 40) * 2;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
     };
 
     f32x4 acc[TN][TM];
-    bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    bf16x8 xf0[TM], wf0[TN], xf1[FRAG_DB ? TM : 1], wf1[FRAG_DB ? TN : 1];
     auto load_frags = [&](const char* sb, int ks, bf16x8* xf, bf16x8* wf) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) xf[t] = *(const bf16x8*)(sb + xoff + t * 2048 + swz[ks]);
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
     };
 
     // paired 16-byte stores + one 8-byte store per row block (always: full tiles) -- the counted wait below relies on it
-    constexpr int EPI_STORES = (TN / 2 + 1) * TM;
+    constexpr int EPI_STORES = GEGLU ? (TN / 4) * TM : (TN / 2 + 1) * TM;
     int g = 0;                     // running K-tile count: LDS buffer parity
     bool stores_pending = false;
     stage(0, 0);
@@ -181,25 +187,31 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
                 glds16((const char*)p.vec1 + (long)n0 * 4 + (unsigned)vVec, vecs + BN * 4 + wn * WTN * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(sb, 1, xf1, wf1);
-            mfmas(xf0, wf0);
-            mfmas(xf1, wf1);
+            if (FRAG_DB) {
+                load_frags(sb, 1, xf1, wf1);
+                mfmas(xf0, wf0);
+                mfmas(xf1, wf1);
+            } else {                 // register budget: one fragment set, reloaded between the k-steps
+                mfmas(xf0, wf0);
+                load_frags(sb, 1, xf0, wf0);
+                mfmas(xf0, wf0);
+            }
         }
         // ---- last K tile: the epilogue's loads are issued under its MFMAs (no LDS-DMA is in flight here) ---------------
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         static_assert(!LN || WTM == 64, "LayerNorm fold: lane l owns row l of its wave's 64 rows");
-        u32x2 ep[LN ? NP : TN * TM];        // the row's LayerNorm partials, or the residual's 8-byte pieces
+        u32x2 ep[LN ? NP : (GEGLU ? 1 : TN * TM)];        // the row's LayerNorm partials, or the residual's 8-byte pieces
         {
             const char* sb = smem + ((g + KT - 1) & 1) * STAGE_BYTES;
             load_frags(sb, 0, xf0, wf0);
-            load_frags(sb, 1, xf1, wf1);
+            if (FRAG_DB) load_frags(sb, 1, xf1, wf1);
             if (LN) {
                 const char* src = (const char*)p.ln_rs + (long)m0 * 8;
 #pragma unroll
                 for (int i = 0; i < NP; ++i) ep[i] = *(const u32x2*)((src + (long)i * p.M * 8) + (unsigned)vLn);
-            } else if (p.R) {
+            } else if (!GEGLU && p.R) {
                 const int so = m0 * p.ldrb + n0 * 2;
 #pragma unroll
                 for (int b = 0; b < TM; ++b)
@@ -209,18 +221,26 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);      // (the epilogue's arithmetic -- and its wait for these loads -- stays below the MFMAs)
             mfmas(xf0, wf0);
-            mfmas(xf1, wf1);
+            if (FRAG_DB) {
+                mfmas(xf1, wf1);
+            } else {
+                load_frags(sb, 1, xf0, wf0);
+                mfmas(xf0, wf0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         g += KT;
 
         // ---- epilogue, phase A: fold everything that was loaded into the fp32 accumulators ------------------------------
-        f32x4 v0[TN], v1[TN];
+        f32x4 v0[TNH], v1[TNH];
+        auto vec_load = [&](int a0) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            v0[a] = *(const f32x4*)(vecs + (wn * WTN + a * 16 + lq * 4) * 4);
-            v1[a] = *(const f32x4*)(vecs + BN * 4 + (wn * WTN + a * 16 + lq * 4) * 4);
-        }
+            for (int a = 0; a < TNH; ++a) {
+                v0[a] = *(const f32x4*)(vecs + (wn * WTN + (a0 + a) * 16 + lq * 4) * 4);
+                v1[a] = *(const f32x4*)(vecs + BN * 4 + (wn * WTN + (a0 + a) * 16 + lq * 4) * 4);
+            }
+        };
+        vec_load(0);
         if (LN) {
             // LayerNorm fold: rstd * (acc - mean * c1[n]) + c2[n]
             float s = 0.f, q = 0.f;
@@ -236,11 +256,15 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
 #pragma unroll
             for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + wave * 512 + (b * 16 + lrow) * 8);
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
+            for (int a0 = 0; a0 < TN; a0 += TNH) {
+                if (a0 > 0) vec_load(a0);
 #pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] = ln_fold(acc[a][b], v0[a], mr[b][0], mr[b][1], v1[a]);
+                for (int a = 0; a < TNH; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) acc[a0 + a][b] = ln_fold(acc[a0 + a][b], v0[a], mr[b][0], mr[b][1], v1[a]);
+            }
         } else {
-            if (p.R) {
+            if (!GEGLU && p.R) {
 #pragma unroll
                 for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -251,10 +275,14 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
                     }
             }
 #pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const f32x4 bv = v0[a] + v1[a];                   // (a null vector was read as zeros)
+            for (int a0 = 0; a0 < TN; a0 += TNH) {
+                if (a0 > 0) vec_load(a0);
 #pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] += bv;
+                for (int a = 0; a < TNH; ++a) {
+                    const f32x4 bv = v0[a] + v1[a];               // (an absent vector is the launcher's zero vector)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) acc[a0 + a][b] += bv;
+                }
             }
         }
 
@@ -273,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
         }
 
         // ---- epilogue, phase B: statistics, convert, store ---------------------------------------------------------------
-        if (!LN && WTM == 64 && p.stats) {
+        if (!LN && !GEGLU && WTM == 64 && p.stats) {
             // GroupNorm block statistics of the bf16-rounded outputs: [M / 64][N][2], this wave's 64 rows = one block
             char* dst = (char*)p.stats + ((long)((em0 + wm * WTM) >> 6) * p.N + en0) * 8 + (unsigned)vSt;
 #pragma unroll
@@ -297,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
                 }
             }
         }
-        if (!LN && p.rowstats) {
+        if (!LN && !GEGLU && p.rowstats) {
             // LayerNorm partials of the bf16-rounded outputs: [2 tiles_n][M][2], per row the (sum, sum of squares) of this
             // N-wave's 80 columns
             char* dst = (char*)p.rowstats + ((long)(etile_n * WAVES_N + wn) * p.M + em0) * 8 + (unsigned)vRs;
@@ -316,41 +344,63 @@ __global__ __launch_bounds__(256, 2) void gemm_lean_kernel(const LeanArgs p) {
                 if (lq == 0) *(f32x2_t*)(dst + b * 16 * 8) = f32x2_t{s, q};
             }
         }
-        // v_permlane16_swap pairs two adjacent 16 x 16 tiles so that a lane owns 8 consecutive columns (16 B) of its row:
-        // after the swap lane group lq holds  0: tile a cols 0-7, 1: tile a+1 cols 0-7, 2: tile a cols 8-15, 3: tile a+1 cols 8-15
-        u32x4 ow[TM][TN / 2];
-        u32x2 on[TM];
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
-#pragma unroll
-            for (int a = 0; a + 1 < TN; a += 2) {
-                const f32x4 vx = acc[a][b], vy = acc[a + 1][b];
-                const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
-                ow[b][a / 2] = u32x4{s0[0], s1[0], s0[1], s1[1]};
-            }
-            const f32x4 v = acc[TN - 1][b];
-            on[b] = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        }
-        if (LN && p.hm_tpc > 0 && etile_n >= p.hm_tpc) {          // tile-uniform: a K or V tile of the q|k|v projection
-            // KV[which][sample][head][token][40]: which = K or V, head0 = first of this tile's four heads
-            const int which = etile_n >= 2 * p.hm_tpc ? 1 : 0;
-            const int head0 = (etile_n - (which + 1) * p.hm_tpc) * 4;
-            const int smp = em0 >> p.hm_tok_shift, tok0 = em0 & ((1 << p.hm_tok_shift) - 1);
-            const int soC = ((((which * p.hm_samples + smp) * p.hm_heads + head0) << p.hm_tok_shift) + tok0) * 80;
+        if constexpr (GEGLU) {
+            // value * gelu(gate) of the accumulator pairs (a, a + 1); two output tiles (four accumulator tiles) are paired by
+            // v_permlane16_swap into 16-byte stores: lane group lq then holds output columns 16 (lq & 1) + 8 (lq >> 1) .. + 7
+            auto geglu_tile = [&](int a, int b) -> u32x2 {
+                const f32x4 va = acc[a][b], vg = acc[a + 1][b];
+                const f32x2_t lo = geglu_pair(f32x2_t{va[0], va[1]}, f32x2_t{vg[0], vg[1]});
+                const f32x2_t hi = geglu_pair(f32x2_t{va[2], va[3]}, f32x2_t{vg[2], vg[3]});
+                return u32x2{pack2bf(lo[0], lo[1]), pack2bf(hi[0], hi[1])};
+            };
+            const int soC = em0 * p.ldcb + en0;                    // (n0 / 2 output columns x 2 bytes)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
 #pragma unroll
-                for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rKV, vH[j], soC + b * 16 * 80, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(on[b], rKV, vH[TN / 2], soC + b * 16 * 80, 0);
+                for (int a = 0; a < TN; a += 4) {
+                    const u32x2 ox = geglu_tile(a, b), oy = geglu_tile(a + 2, b);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ox[0], oy[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rC, vCg + a * 16, soC + b * 16 * p.ldcb, 0);
+                }
             }
         } else {
-            const int soC = em0 * p.ldcb + en0 * 2;
+        // v_permlane16_swap pairs two adjacent 16 x 16 tiles so that a lane owns 8 consecutive columns (16 B) of its row:
+            // after the swap lane group lq holds  0: tile a cols 0-7, 1: tile a+1 cols 0-7, 2: tile a cols 8-15, 3: tile a+1 cols 8-15
+            u32x4 ow[TM][TN / 2];
+            u32x2 on[TM];
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
 #pragma unroll
-                for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rC, vCw + j * 64, soC + b * 16 * p.ldcb, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(on[b], rC, vCn + (TN - 1) * 32, soC + b * 16 * p.ldcb, 0);
+                for (int a = 0; a + 1 < TN; a += 2) {
+                    const f32x4 vx = acc[a][b], vy = acc[a + 1][b];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[0], vx[1]), pack2bf(vy[0], vy[1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
+                    ow[b][a / 2] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+                const f32x4 v = acc[TN - 1][b];
+                on[b] = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            }
+            if (LN && p.hm_tpc > 0 && etile_n >= p.hm_tpc) {          // tile-uniform: a K or V tile of the q|k|v projection
+                // KV[which][sample][head][token][40]: which = K or V, head0 = first of this tile's four heads
+                const int which = etile_n >= 2 * p.hm_tpc ? 1 : 0;
+                const int head0 = (etile_n - (which + 1) * p.hm_tpc) * 4;
+                const int smp = em0 >> p.hm_tok_shift, tok0 = em0 & ((1 << p.hm_tok_shift) - 1);
+                const int soC = ((((which * p.hm_samples + smp) * p.hm_heads + head0) << p.hm_tok_shift) + tok0) * 80;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+#pragma unroll
+                    for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rKV, vH[j], soC + b * 16 * 80, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(on[b], rKV, vH[TN / 2], soC + b * 16 * 80, 0);
+                }
+            } else {
+                const int soC = em0 * p.ldcb + en0 * 2;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+#pragma unroll
+                    for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rC, vCw + j * 64, soC + b * 16 * p.ldcb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(on[b], rC, vCn + (TN - 1) * 32, soC + b * 16 * p.ldcb, 0);
+                }
             }
         }
         if (!more) break;

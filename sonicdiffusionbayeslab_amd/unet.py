@@ -175,6 +175,9 @@ class HipUNet2DConditionModel:
         return out
 
     def set_fp8_scales(self, scales: Dict[str, float]) -> None:
+        # the e4m3 activation tensors get their names when a plan is built: make sure one exists (batch 1, no DeepCache)
+        if self._lib.sd_unet_workspace_bytes(self._handle, 1, -1) < 0:
+            _lib.check(-1, "sd_unet_workspace_bytes")
         for k, v in scales.items():
             _lib.check(self._lib.sd_unet_set_fp8_scale(self._handle, k.encode(), float(v)), f"sd_unet_set_fp8_scale({k})")
 

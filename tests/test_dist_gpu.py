@@ -30,7 +30,7 @@ def _run_method(config_name, nprompts, batch, overrides=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.chdir(root)
     # two levels of the SD-1.5 widths: this file tests the sharding, not the kernels (a fifth of the parameters to generate,
-    # pack and upload in each of the five processes a case starts)
+    # pack and upload in every process)
     ucfg = UNetConfig(sample_size=16, block_out_channels=(320, 640), attn_levels=(True, False))
     sd = make_synthetic_state_dict(ucfg, seed=1234)
     M.StableDiffusionModel.from_pretrained = classmethod(
@@ -50,44 +50,59 @@ def _run_method(config_name, nprompts, batch, overrides=None):
     return torch.stack(images), float(m.time_metric.compute())
 
 
-def _worker(rank, world, port, config_name, nprompts, batch, q, overrides=None, backend="gloo", force=False):
+def _worker(rank, world, port, cases, q, backend="gloo", force=False):
+    """One rank: every case in turn on ONE process group (a case = (config, prompts, batch, overrides))."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SD_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if force:
         os.environ["SD_DIST_FORCE_INIT"] = "1"
     import torch.distributed as dist
-    out, t = _run_method(config_name, nprompts, batch, overrides)
-    assert dist.is_initialized() and dist.get_backend() == backend and dist.get_world_size() == world
-    q.put((rank, out.cpu(), t))
+    for idx, (config_name, nprompts, batch, overrides) in enumerate(cases):
+        out, t = _run_method(config_name, nprompts, batch, overrides)
+        assert dist.is_initialized() and dist.get_backend() == backend and dist.get_world_size() == world
+        q.put((rank, idx, out.cpu(), t))
     dist.barrier()
     dist.destroy_process_group()
 
 
 SDE = {"algorithm_type": "sde-dpmsolver++"}       # a Gaussian per step from the shared generator (src/schedulers.py:134-147)
+CASES = [("ddim_config.yaml", 5, 5, None),                   # CFG, ragged 3 + 2
+         ("consistency_model_config.yaml", 6, 4, None),      # LCM noise, 2 batches
+         ("dpm_solver_config.yaml", 4, 3, SDE)]              # stochastic DPM-Solver: ragged 2 + 1, then a batch whose rank 1 is empty
 
 
-@pytest.mark.parametrize("config_name,nprompts,batch,overrides", [
-    ("ddim_config.yaml", 5, 5, None),                   # CFG, ragged 3 + 2
-    ("consistency_model_config.yaml", 6, 4, None),      # LCM noise, 2 batches
-    ("dpm_solver_config.yaml", 4, 3, SDE)])             # stochastic DPM-Solver: ragged 2 + 1, then a batch whose rank 1 is empty
-def test_world2_sharded_generate_matches_single_process(config_name, nprompts, batch, overrides):
+@pytest.fixture(scope="module")
+def world2_runs():
+    """The single-process references of every case (this process), then ONE pair of ranks that runs every case on one
+    process group: three processes touch the GPU instead of the five-per-case of round 3 (GPU-box process guard, run time)."""
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SD_DIST_FORCE_INIT"):
         os.environ.pop(k, None)
-    want, t1 = _run_method(config_name, nprompts, batch, overrides)
+    want = [_run_method(*c) for c in CASES]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, config_name, nprompts, batch, q, overrides)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, CASES, q)) for r in range(2)]
     [p.start() for p in ps]
-    outs = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(2))}
+    got = {}
+    for _ in range(2 * len(CASES)):
+        rank, idx, out, t = q.get(timeout=600)
+        got[(rank, idx)] = (out, t)
     [p.join(120) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
+    return want, got
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)), ids=[c[0] for c in CASES])
+def test_world2_sharded_generate_matches_single_process(world2_runs, idx):
     from tests.util import rel_l2
-    assert torch.equal(outs[0][0], outs[1][0]), "both ranks must hold the same gathered batch"
-    err = rel_l2(outs[0][0], want)
+    want, got = world2_runs
+    config_name, nprompts = CASES[idx][0], CASES[idx][1]
+    (o0, t0), (o1, t1) = got[(0, idx)], got[(1, idx)]
+    assert torch.equal(o0, o1), "both ranks must hold the same gathered batch"
+    err = rel_l2(o0, want[idx][0])
     print(f"{config_name}: world-2 vs world-1 rel-L2 {err:.3e} over {nprompts} images")
-    assert outs[0][0].shape == want.shape and err < SHARD_TOL
-    assert outs[0][1] > 0 and outs[0][1] == outs[1][1]
+    assert o0.shape == want[idx][0].shape and err < SHARD_TOL
+    assert t0 > 0 and t0 == t1
 
 
 def test_rccl_world1_rehearsal_of_the_gather_path():
@@ -100,9 +115,9 @@ def test_rccl_world1_rehearsal_of_the_gather_path():
     want, _ = _run_method("ddim_config.yaml", 3, 3)
     ctx = mp.get_context("spawn")            # the child touches the GPU only after it has started (no exec of a GPU process)
     q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), "ddim_config.yaml", 3, 3, q, None, "nccl", True))
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), [("ddim_config.yaml", 3, 3, None)], q, "nccl", True))
     p.start()
-    rank, got, t = q.get(timeout=600)
+    rank, _, got, t = q.get(timeout=600)
     p.join(120)
     assert p.exitcode == 0
     assert got.shape == want.shape and torch.equal(got, want) and t > 0

@@ -639,3 +639,32 @@ def test_model_registry_entries_are_the_pipeline_classes():
             "stable_diffusion_model_skip_timesteps": models.StableDiffusionModelSkipTimesteps}
     for name, cls in want.items():
         assert models_registry[name] is cls and isinstance(cls, type) and callable(getattr(cls, "from_pretrained"))
+
+
+def test_attention_inline_asm_reads_are_covered_by_their_counted_waits():
+    """csrc/attention.hip (SD_ATTN_VARIANT 7, the 64x64 self-attention) reads its V^T fragments with inline-asm
+    ds_read_b64_tr_b16 and waits for them a group later with literal lgkmcnt counts; build.py checks the compiler's output on
+    every build (tools/check_lds_waits.py) and keeps the checked .s: the same check here, plus two mutations of that .s
+    that the checker must catch (a wait that is one too lax; a copy of a fragment register ahead of its wait)."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_lds_waits", os.path.join(root, "tools", "check_lds_waits.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    path = os.path.join(root, "sonicdiffusionbayeslab_amd", "lib", "attention.s")
+    if not os.path.exists(path):
+        from sonicdiffusionbayeslab_amd.build import build_library
+        build_library()
+    text = open(path).read()
+    kernels = list(chk.kernel_bodies(text, "attn_pipe40_kernelILi7"))
+    assert len(kernels) == 1
+    name, body = kernels[0]
+    errs, n_tr = chk.check_kernel(name, body)
+    assert n_tr >= 32 and errs == [], errs[:3]
+    lax = body.replace("s_waitcnt lgkmcnt(6)", "s_waitcnt lgkmcnt(7)", 1)
+    assert lax != body and chk.check_kernel(name, lax)[0]
+    m = re.search(r"ds_read_b64_tr_b16 (v\[(\d+):\d+\]),[^\n]*\n", body)
+    early = body[:m.end()] + f"\tv_mov_b32_e32 v255, v{m.group(2)}\n" + body[m.end():]
+    assert chk.check_kernel(name, early)[0]
