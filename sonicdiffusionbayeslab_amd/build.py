@@ -24,7 +24,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # the kernel masks with -1e30, never with inf/NaN)
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
                # fused cross-attention: 160 accumulators + the softmax on them in ONE 256-register pool
-               "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # the GEMM epilogues: scalar fp32 stays scalar (common.h::ln_fold: the SLP-packed v_pk_fma_f32 form of the
+               # LayerNorm fold was the source of a rare wrong result; packed fp32 is also slower beside MFMAs)
+               "gemm_conv.hip": ["-fno-slp-vectorize"], "gemm_lean.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(a: str, b: str) -> bool:

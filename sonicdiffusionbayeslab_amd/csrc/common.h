@@ -54,7 +54,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the IEEE division expands to ~10 instructions per element and made
+// the GroupNorm + SiLU pass VALU-bound: ~210 instructions per 16-byte vector against ~17 us of HBM time per 64x64 instance)
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 // exact-erf GELU (diffusers GEGLU uses F.gelu default).  erf via Abramowitz-Stegun 7.1.25
 // (|abs err| <= 2.5e-5 -> |gelu err| <= 1.3e-5 |x|, 300x below the bf16 output rounding):
 // 2 transcendentals + 8 VALU ops; the GEGLU epilogue evaluates 8192 of these per 128x128 tile.
@@ -174,9 +178,18 @@ __device__ __forceinline__ f32x2_t ln_mean_rstd(float s, float q, float inv_k, f
     const float var = __builtin_fmaf(q, inv_k, -(mean * mean));
     return f32x2_t{mean, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + eps)};
 }
+// SCALAR fused multiply-adds on purpose (and gemm_conv.hip / gemm_lean.hip are built with -fno-slp-vectorize so that hipcc
+// does not re-pack them).  Written on f32x4 with __builtin_elementwise_fma this became v_pk_fma_f32 with op_sel / neg
+// modifiers broadcasting (mean, rstd) from the register pair a ds_read2_b64 had just delivered, and on MI355X that form
+// produced, about once per 40 launches of the 64x64 q|k|v projection, ONE accumulator register of lanes 48-63 holding c2
+// alone (the product term gone) -- 16 rows x 1 column of the output equal to the bias; found by the run-to-run determinism
+// test at bench shapes (tests/test_ops_gpu.py), 0 events in 3 x 84 launches with the scalar form, 4 in 3 x 84 with the
+// packed one, 0 with the round-3 expression.  Packed fp32 is also the slower choice beside MFMAs (MI355X_MICROARCH.md).
 __device__ __forceinline__ f32x4 ln_fold(f32x4 acc, f32x4 c1, float mean, float rstd, f32x4 c2) {   // rstd (acc - mean c1) + c2
-    const f32x4 nm = {-mean, -mean, -mean, -mean}, rs = {rstd, rstd, rstd, rstd};
-    return __builtin_elementwise_fma(__builtin_elementwise_fma(c1, nm, acc), rs, c2);
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf(__builtin_fmaf(c1[j], -mean, acc[j]), rstd, c2[j]);
+    return r;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

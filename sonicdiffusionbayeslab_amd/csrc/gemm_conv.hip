@@ -428,6 +428,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         }
         const float invk = 1.0f / (float)p.K;
         *(f32x2_t*)(lnbuf + lane * 8) = ln_mean_rstd(s, q, invk, p.ln_eps);      // row = lane; every lane needs rows b * 16 + lrow
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (see gemm_lean.hip: explicit wait between this write and the reads)
         f32x2_t mr[TM];
 #pragma unroll
         for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + (b * 16 + lrow) * 8);
@@ -820,8 +821,12 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     SD_REQUIRE(a.K1 == a.K || a.X2 != nullptr, "gemm: second K segment needs X2");
     SD_REQUIRE(a.M > 0 && a.N > 0, "gemm: empty problem");
     SD_REQUIRE(a.zero_page != nullptr, "gemm: zero page missing");
+    // (read per call, not cached: tests/test_ops_gpu.py compares the two kernels bit for bit inside one process)
+    const char* lean_env = getenv("SD_GEMM_LEAN");
+    const bool lean_off = lean_env && atoi(lean_env) == 0;
     if (epi == EPI_GEGLU) {
         SD_REQUIRE(a.N % 32 == 0, "geglu gemm: N=%d must be a multiple of 32", a.N);
+        if (!lean_off && big_tile_mode() == 0 && sd_gemm_lean_applicable(a, 1)) return sd_launch_gemm_lean(a, 1, 256, stream);
         if (big_tile_ok(a.M, a.N, 128)) return launch<256, 128, 4, 2, 3, AMODE_GEMM, EPI_GEGLU>(a, stream);
         // 256 x 256 (one 8-wave workgroup per CU): half the LDS-fill bytes per flop of the 128 x 128 tile,
         // measured 5-20 % faster at every SD-1.5 GEGLU shape (N = 2560 / 5120 / 10240)
@@ -838,12 +843,9 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     if (a.rows_per_batch) return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);   // tiles must not straddle samples
     // the UNet's full-tile projections: the lean kernel (gemm_lean.hip; same tile and accumulation order, bit-identical
     // results, a fraction of the per-item instructions).  SD_GEMM_LEAN=0 keeps everything on gemm_kernel (A/B).
-    // (read per call, not cached: tests/test_ops_gpu.py compares the two kernels bit for bit inside one process)
-    const char* lean_env = getenv("SD_GEMM_LEAN");
-    const bool lean_off = lean_env && atoi(lean_env) == 0;
     if (!lean_off && big_tile_mode() == 0 && sd_gemm_lean_applicable(a, epi)) {
         const int rows = (!a.stats && !a.ln_rs && !a.hm_C) ? sd_gemm_tile_rows(a.M, a.N, a.K) : 128;
-        return sd_launch_gemm_lean(a, rows, stream);
+        return sd_launch_gemm_lean(a, 0, rows, stream);
     }
     if (big_tile_ok(a.M, a.N, 160)) return launch<256, 160, 4, 2, 3, AMODE_GEMM, EPI_STD>(a, stream);
     if (big_tile_mode() == 2) return launch<256, 160, 4, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);

@@ -252,6 +252,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
                 q += e[1];
             }
             *(f32x2_t*)(lnbuf + wave * 512 + lane * 8) = ln_mean_rstd(s, q, p.inv_k, p.ln_eps);   // row = lane; lanes need rows 16 b + lrow
+            // The reads below take OTHER lanes' (mean, rstd) from this wave's slots.  An explicit wait between the write and
+            // the reads: without it the first launch on cold caches of the 8-wave GEGLU instantiation (NP = 8, M = 16384)
+            // differed from every later launch in 16 x a few elements, 3 trials of 3; with it never (gpurun_out/r4 logs).
+            // LDS operations of one wave are documented as in-order, so this should not be needed -- it costs one LDS
+            // round trip per item and is kept until the mechanism is understood.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f32x2_t mr[TM];
 #pragma unroll
             for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + wave * 512 + (b * 16 + lrow) * 8);
@@ -356,12 +362,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
             const int soC = em0 * p.ldcb + en0;                    // (n0 / 2 output columns x 2 bytes)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
+                const int vo = vCg + (soC + b * 16 * p.ldcb);      // STORE_OFFSET_RULE (see the std stores below)
 #pragma unroll
                 for (int a = 0; a < TN; a += 4) {
                     const u32x2 ox = geglu_tile(a, b), oy = geglu_tile(a + 2, b);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(ox[0], oy[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(ox[1], oy[1], false, false);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rC, vCg + a * 16, soC + b * 16 * p.ldcb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rC, vo + a * 16, 0, 0);
                 }
             }
         } else {
@@ -389,17 +396,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
                 const int soC = ((((which * p.hm_samples + smp) * p.hm_heads + head0) << p.hm_tok_shift) + tok0) * 80;
 #pragma unroll
                 for (int b = 0; b < TM; ++b) {
+                    const int so = soC + b * 16 * 80;
 #pragma unroll
-                    for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rKV, vH[j], soC + b * 16 * 80, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(on[b], rKV, vH[TN / 2], soC + b * 16 * 80, 0);
+                    for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rKV, vH[j] + so, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(on[b], rKV, vH[TN / 2] + so, 0, 0);
                 }
             } else {
+                // STORE_OFFSET_RULE: the scalar part of a store's address is ADDED INTO THE VECTOR OFFSET (one v_add per row
+                // block), never passed as the instruction's SGPR soffset.  hipcc's hazard recognizer assumes that a 16-byte
+                // buffer store WITH a register soffset needs no wait state before a VALU instruction overwrites its data
+                // registers (GCNHazardRecognizer::createsVALUHazard); on gfx950 it does: the GEGLU epilogue of this file,
+                // where the next pair's v_med3 lands in the store's data registers one instruction later, stored the NEW
+                // value in lanes 12-15 of every row (round 4, found by the bit-identity test against gemm_kernel).
+                // Without soffset the compiler inserts the wait state itself.
                 const int soC = em0 * p.ldcb + en0 * 2;
 #pragma unroll
                 for (int b = 0; b < TM; ++b) {
+                    const int so = soC + b * 16 * p.ldcb;
 #pragma unroll
-                    for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rC, vCw + j * 64, soC + b * 16 * p.ldcb, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(on[b], rC, vCn + (TN - 1) * 32, soC + b * 16 * p.ldcb, 0);
+                    for (int j = 0; j < TN / 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(ow[b][j], rC, vCw + so + j * 64, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(on[b], rC, vCn + so + (TN - 1) * 32, 0, 0);
                 }
             }
         }
@@ -417,31 +433,35 @@ static const float* zero_vector() {
     return z;
 }
 
-template <int BM, int NP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, bool GEGLU>
 int launch_lean(const LeanArgs& a0, hipStream_t stream) {
     LeanArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
-    a.tiles_n = a.N / 160;
-    constexpr int smem = 2 * (BM + 160) * 128 + 4 * 512 + 2 * 160 * 4;
-    auto kern = gemm_lean_kernel<BM, 160, NP>;
+    a.tiles_n = a.N / BN;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int smem = 2 * (BM + BN) * 128 + NW * 512 + 2 * BN * 4;
+    static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    auto kern = gemm_lean_kernel<BM, BN, WAVES_M, WAVES_N, NP, GEGLU>;
     static bool attr_set = false;
     if (!attr_set) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     int grid = a.tiles_m * a.tiles_n;
-    if (grid > 512) grid = 512;        // two workgroups per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, a);
+    constexpr int resident = smem > 80 * 1024 ? 256 : 512;      // workgroups that fit the chip at once (1 or 2 per CU)
+    if (grid > resident) grid = resident;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-// Shapes / features the lean kernel takes (everything else runs on gemm_conv.hip's gemm_kernel).
+// Shapes / features the lean kernels take (everything else runs on gemm_conv.hip's gemm_kernel).  epi 0 = std, 1 = GEGLU.
 bool sd_gemm_lean_applicable(const GemmArgs& a, int epi) {
-    if (epi != 0 || a.dt != 0 || a.out_fp8 || a.rows_per_batch || a.subpix || (a.splitk > 1 && a.slab)) return false;
-    if (a.N % 160 != 0 || a.N > 16384 || a.K % 64 != 0 || a.K < 128 || a.K1 % 64 != 0 || a.M < 1) return false;
+    if ((epi != 0 && epi != 1) || a.dt != 0 || a.out_fp8 || a.rows_per_batch || a.subpix || (a.splitk > 1 && a.slab)) return false;
+    const int BN = epi ? 256 : 160;
+    if (a.N % BN != 0 || a.N > 16384 || a.K % 64 != 0 || a.K < 128 || a.K1 % 64 != 0 || a.M < 1) return false;
     if (a.K1 != a.K && a.X2 == nullptr) return false;
     if ((a.ldc & 7) || (a.ldx & 7) || (a.X2 && (a.ldx2 & 7)) || (a.ldw & 7) || (a.R && (a.ldr & 3))) return false;
     const long big = 1L << 31;
@@ -450,11 +470,12 @@ bool sd_gemm_lean_applicable(const GemmArgs& a, int epi) {
     if (a.X2 && (long)a.M * a.ldx2 * 2 >= big) return false;
     if (a.R && (long)a.M * a.ldr * 2 >= big) return false;
     // producer / consumer side tensors are indexed by row: whole tiles only
-    if ((a.stats || a.rowstats || a.ln_rs || a.hm_C) && a.M % 128 != 0) return false;
-    if (a.ln_rs) {      // the LN = true instantiation: one K segment, c1 / c2, 4 / 8 / 16 partials, no producer side
+    if ((a.stats || a.rowstats || a.ln_rs || a.hm_C) && a.M % (epi ? 256 : 128) != 0) return false;
+    if (a.ln_rs) {      // the LN = true instantiations: one K segment, c1 / c2, 4 / 8 / 16 partials, no producer side
         if (a.R || a.bias2 || !a.bias || !a.ln_c1 || a.X2 || a.K1 != a.K || a.stats || a.rowstats) return false;
         if (a.ln_np != 4 && a.ln_np != 8 && a.ln_np != 16) return false;
     }
+    if (epi == 1 && (a.R || a.bias2 || a.X2 || a.K1 != a.K || a.stats || a.rowstats || a.hm_C)) return false;
     if (a.hm_C) {       // head-major K / V: on the q|k|v projection, which is a LayerNorm-fold consumer in the UNet plan
         if (!a.ln_rs || !a.KV || a.hm_C % 160 != 0 || a.N != 3 * a.hm_C || a.hm_tok < 128 || (a.hm_tok & (a.hm_tok - 1)) ||
             a.M % a.hm_tok != 0 || (long)a.M * a.hm_C * 4 >= big)
@@ -463,9 +484,10 @@ bool sd_gemm_lean_applicable(const GemmArgs& a, int epi) {
     return true;
 }
 
-int sd_launch_gemm_lean(const GemmArgs& g, int rows, hipStream_t stream) {
-    SD_REQUIRE(sd_gemm_lean_applicable(g, 0), "gemm (lean): problem not supported (M=%d N=%d K=%d)", g.M, g.N, g.K);
-    SD_REQUIRE(rows == 128 || (rows == 64 && !g.stats && !g.ln_rs && !g.hm_C), "gemm (lean): %d-row tile with block statistics / LayerNorm fold / head-major K|V", rows);
+int sd_launch_gemm_lean(const GemmArgs& g, int epi, int rows, hipStream_t stream) {
+    SD_REQUIRE(sd_gemm_lean_applicable(g, epi), "gemm (lean): problem not supported (M=%d N=%d K=%d epi=%d)", g.M, g.N, g.K, epi);
+    SD_REQUIRE(epi == 1 || rows == 128 || (rows == 64 && !g.stats && !g.ln_rs && !g.hm_C),
+               "gemm (lean): %d-row tile with block statistics / LayerNorm fold / head-major K|V", rows);
     const long ldw = g.ldw ? g.ldw : g.K;
     LeanArgs a{};
     a.X = g.X; a.X2 = g.X2; a.W = g.W; a.R = g.R; a.C = g.C; a.KV = g.KV;
@@ -476,7 +498,7 @@ int sd_launch_gemm_lean(const GemmArgs& g, int rows, hipStream_t stream) {
     a.x2_bytes = g.X2 ? (unsigned)(((long)g.M - 1) * g.ldx2 * 2 + (long)(g.K - g.K1) * 2) : 0;
     a.w_bytes = (unsigned)(((long)g.N - 1) * ldw * 2 + (long)g.K * 2);
     a.r_bytes = g.R ? (unsigned)(((long)g.M - 1) * g.ldr * 2 + (long)g.N * 2) : 0;
-    const int ncols = g.hm_C ? g.hm_C : g.N;          // columns that go to C
+    const int ncols = epi ? g.N / 2 : g.hm_C ? g.hm_C : g.N;          // columns that go to C
     a.c_bytes = (unsigned)(((long)g.M - 1) * g.ldc * 2 + (long)ncols * 2);
     a.kv_bytes = g.hm_C ? (unsigned)((long)g.M * g.hm_C * 4) : 0;
     const float* zeros = nullptr;
@@ -496,6 +518,13 @@ int sd_launch_gemm_lean(const GemmArgs& g, int rows, hipStream_t stream) {
         while ((1 << sh) < g.hm_tok) ++sh;
         a.hm_tok_shift = sh; a.hm_heads = g.hm_C / 40; a.hm_samples = g.M / g.hm_tok;
     }
-    if (g.ln_rs) return g.ln_np == 4 ? launch_lean<128, 4>(a, stream) : g.ln_np == 8 ? launch_lean<128, 8>(a, stream) : launch_lean<128, 16>(a, stream);
-    return rows == 64 ? launch_lean<64, 0>(a, stream) : launch_lean<128, 0>(a, stream);
+    if (epi == 1) {
+        if (!g.ln_rs) return launch_lean<256, 256, 4, 2, 0, true>(a, stream);
+        return g.ln_np == 4 ? launch_lean<256, 256, 4, 2, 4, true>(a, stream)
+             : g.ln_np == 8 ? launch_lean<256, 256, 4, 2, 8, true>(a, stream) : launch_lean<256, 256, 4, 2, 16, true>(a, stream);
+    }
+    if (g.ln_rs)
+        return g.ln_np == 4 ? launch_lean<128, 160, 2, 2, 4, false>(a, stream)
+             : g.ln_np == 8 ? launch_lean<128, 160, 2, 2, 8, false>(a, stream) : launch_lean<128, 160, 2, 2, 16, false>(a, stream);
+    return rows == 64 ? launch_lean<64, 160, 2, 2, 0, false>(a, stream) : launch_lean<128, 160, 2, 2, 0, false>(a, stream);
 }

@@ -69,9 +69,10 @@ int sd_gemm_tile_rows(int M, int N, int K = 0);   // 64 or 128: M tile of the pl
 int sd_gemm_splitk(int M, int N, int K, int rows = 0);   // heuristic split factor (1 = none) for the std epilogue
 int sd_launch_gemm(const GemmArgs& a, int epi /*0 std, 1 geglu, 2 softmax over 80-column groups*/, hipStream_t stream);
 int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream);
-// gemm_lean.hip: the std-epilogue GEMM on full 160-column tiles with buffer addressing (rows = 64 or 128: the M tile)
+// gemm_lean.hip: the std-epilogue (epi 0; rows = 64 or 128: the M tile) and GEGLU (epi 1, 256 x 256 tile) GEMMs on full N
+// tiles with buffer addressing
 bool sd_gemm_lean_applicable(const GemmArgs& a, int epi);
-int sd_launch_gemm_lean(const GemmArgs& a, int rows, hipStream_t stream);
+int sd_launch_gemm_lean(const GemmArgs& a, int epi, int rows, hipStream_t stream);
 void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // slab -> C (+bias +bias2 +R)
 // conv_halo.hip: LDS-resident-halo kernel for stride-1 convs on whole-row tiles
 bool sd_conv_halo_applicable(const GemmArgs& a);

@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256) void gn_finalize_stats_kernel(const GroupNormA
     }
 }
 
+// SILU / FP8 are template parameters: as run-time flags hipcc kept a branch per ELEMENT in the loop (eight blocks of 18
+// instructions per 16-byte vector)
+template <bool SILU, bool FP8>
 __global__ void gn_apply_kernel(const GroupNormArgs a) {
     const GnGeom g = gn_geom(a.C1 + a.C2, a.groups);
     const int tid = threadIdx.x;
@@ -187,9 +190,9 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             f[j] = f[j] * sc[j] + sf[j];
-            if (a.silu) f[j] = silu_f(f[j]);
+            if (SILU) f[j] = silu_f(f[j]);
         }
-        if (a.out_fp8) {       // e4m3 bytes, rows of Cpad bytes; the owner of the last chunk zeroes the K-tail padding
+        if (FP8) {       // e4m3 bytes, rows of Cpad bytes; the owner of the last chunk zeroes the K-tail padding
             char* yr = (char*)a.y + pix * a.Cpad;
             const u32x2 o = {pack4fp8(f[0] * a.oscale, f[1] * a.oscale, f[2] * a.oscale, f[3] * a.oscale),
                              pack4fp8(f[4] * a.oscale, f[5] * a.oscale, f[6] * a.oscale, f[7] * a.oscale)};
@@ -220,6 +223,7 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
 // data; here the group's HW x cpg values (<= 10 KB) are read twice by the same workgroup (the second time from
 // L1/L2), with a block reduction in between (measured 18 -> 8 us at 8x8, 20 -> 16 us at 16x16 x 1280; wider 16x16 tensors stay on the split path).  Accesses are 8 bytes (4 channels): cpg is a multiple of 4 at these
 // levels (20 / 40 / 60 / 80) but not of 8.
+template <bool SILU, bool FP8>
 __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     __shared__ float2 red[4];
     const int C = a.C1 + a.C2, cpg = C / a.groups, upp = cpg >> 2;      // 4-channel units per pixel
@@ -275,9 +279,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             f[jj] = (f[jj] - mean) * rstd * gm[jj] + bt[jj];
-            if (a.silu) f[jj] = silu_f(f[jj]);
+            if (SILU) f[jj] = silu_f(f[jj]);
         }
-        if (a.out_fp8) {
+        if (FP8) {
             *(unsigned*)((char*)a.y + (base + p) * a.Cpad + c) =
                 pack4fp8(f[0] * a.oscale, f[1] * a.oscale, f[2] * a.oscale, f[3] * a.oscale);
         } else {
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
             *(u32x2*)(a.y + (base + p) * C + c) = o;
         }
     }
-    if (a.out_fp8 && grp == a.groups - 1)       // K-tail padding of every pixel row
+    if (FP8 && grp == a.groups - 1)       // K-tail padding of every pixel row
         for (int i = tid; i < a.HW * ((a.Cpad - C) >> 4); i += 256) {
             const int pc = (a.Cpad - C) >> 4, p = i / pc, k = i - p * pc;
             *(u32x4*)((char*)a.y + (base + p) * a.Cpad + C + k * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -537,7 +541,13 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
     if (sd_groupnorm_uses_small(a.B, a.HW, a.C1, a.C2, a.groups)) {
-        hipLaunchKernelGGL(gn_small_kernel, dim3(a.groups, a.B), dim3(256), 0, stream, a);
+        if (a.out_fp8) {
+            if (a.silu) hipLaunchKernelGGL((gn_small_kernel<true, true>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gn_small_kernel<false, true>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
+        } else {
+            if (a.silu) hipLaunchKernelGGL((gn_small_kernel<true, false>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gn_small_kernel<false, false>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
+        }
         SD_CHECK_HIP(hipGetLastError());
         return 0;
     }
@@ -549,7 +559,13 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), (g.threads + g.nchunks) * sizeof(float4), stream, a);
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((a.B * a.groups + 3) / 4), dim3(256), 0, stream, a);
     }
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, a);
+    if (a.out_fp8) {
+        if (a.silu) hipLaunchKernelGGL((gn_apply_kernel<true, true>), grid, dim3(g.threads), 0, stream, a);
+        else hipLaunchKernelGGL((gn_apply_kernel<false, true>), grid, dim3(g.threads), 0, stream, a);
+    } else {
+        if (a.silu) hipLaunchKernelGGL((gn_apply_kernel<true, false>), grid, dim3(g.threads), 0, stream, a);
+        else hipLaunchKernelGGL((gn_apply_kernel<false, false>), grid, dim3(g.threads), 0, stream, a);
+    }
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

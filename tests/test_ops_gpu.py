@@ -395,6 +395,72 @@ def test_gemm_lean_layernorm_fold_and_headmajor_kv(sdlib, B, tokens, C, mean):
                 assert torch.equal(kv[which], want)
 
 
+@pytest.mark.parametrize("M,C,fold", [(512, 320, True), (256, 640, True), (256, 1280, True), (512, 320, False), (300, 640, False)])
+def test_gemm_lean_geglu_kernel_is_bit_identical_to_the_general_kernel(sdlib, M, C, fold):
+    """The GEGLU projection (ff.net.0.proj, N = 8 C packed [16 value | 16 gate]) on the lean 256 x 256 kernel of
+    csrc/gemm_lean.hip -- with the LayerNorm fold (4 / 8 / 16 row partials: norm3 -> GEGLU as the plan runs it) and with a
+    plain bias (incl. an M tail) -- against fp32 torch and, bit for bit, against gemm_kernel's GEGLU instantiation."""
+    import os
+    g = torch.Generator().manual_seed(M + C)
+    N, H = 8 * C, 4 * C
+    h = r16(torch.randn(M, C, generator=g) * 1.5 + 0.4)
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    b = torch.randn(N, generator=g)
+    idx = torch.tensor([(q // 32) * 16 + q % 32 if q % 32 < 16 else H + (q // 32) * 16 + q % 32 - 16 for q in range(N)])
+    outs = []
+    if fold:
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        z = F.layer_norm(h, (C,), gamma, beta, 1e-5) @ r16(w).t() + b
+        wg, c1, c2 = fold_layernorm(w[idx], gamma, beta, b[idx])
+        parts = 2 * (C // 160)
+        hh = h.view(M, parts, C // parts)
+        rs = dev(torch.stack([hh.sum(2), (hh * hh).sum(2)], dim=2).permute(1, 0, 2).contiguous())
+        hd, wd, c1d, c2d = dev(h, torch.bfloat16), dev(wg, torch.bfloat16), dev(c1), dev(c2)
+    else:
+        z = h @ r16(w).t() + b
+        hd, wd, bd = dev(h, torch.bfloat16), dev(w[idx].contiguous(), torch.bfloat16), dev(b[idx].contiguous())
+    ref = z[:, :H] * F.gelu(z[:, H:])
+    for lean in ("1", "0"):
+        os.environ["SD_GEMM_LEAN"] = lean
+        try:
+            out = torch.full((M, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+            if fold:
+                _lib.check(sdlib.sd_op_gemm_ln(stream(), P(hd), C, P(wd), P(c1d), P(c2d), P(rs), parts, 1e-5, P(out), H, M, N, C, 1))
+            else:
+                _lib.check(sdlib.sd_op_gemm(stream(), P(hd), C, None, 0, C, P(wd), P(bd), None, None, 0, P(out), H, M, N, C, 1))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SD_GEMM_LEAN", None)
+        outs.append(out)
+    assert torch.isfinite(outs[0].float()).all() and rel_l2(outs[0], ref) < TOL
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,C,epi", [(16384, 640, 1), (65536, 320, 0), (16384, 640, 0), (4096, 1280, 1)])
+def test_layernorm_fold_gemms_are_run_to_run_deterministic_at_bench_shapes(sdlib, M, C, epi):
+    """The LayerNorm-fold consumers at the bench's own shapes (several work items per workgroup, cold caches on the first
+    launch): six launches into six fresh tensors give the same bits.  Round 4 found the first launch of the 8-wave GEGLU
+    instantiation differing from the later ones in a few dozen elements (a timing-dependent hazard around the per-wave
+    (mean, rstd) exchange through LDS, csrc/gemm_lean.hip); the small-shape reproducibility test of test_unet_gpu.py never
+    reaches these grids."""
+    g = torch.Generator(device="cuda").manual_seed(M + C + epi)
+    N = 8 * C if epi else 3 * C
+    H = N // 2 if epi else N
+    x = (torch.randn(M, C, device="cuda", generator=g) * 1.5 + 0.4).to(torch.bfloat16)
+    w = (torch.randn(N, C, device="cuda", generator=g) / math.sqrt(C)).to(torch.bfloat16)
+    c1, c2 = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    parts = 2 * (C // 160)
+    xf = x.float().view(M, parts, C // parts)
+    rs = torch.stack([xf.sum(2), (xf * xf).sum(2)], dim=2).permute(1, 0, 2).contiguous()
+    outs = [torch.full((M, H), float("nan"), device="cuda", dtype=torch.bfloat16) for _ in range(6)]
+    for out in outs:
+        _lib.check(sdlib.sd_op_gemm_ln(stream(), P(x), C, P(w), P(c1), P(c2), P(rs), parts, 1e-5, P(out), H, M, N, C, epi))
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    for out in outs[1:]:
+        assert torch.equal(out, outs[0])
+
+
 @pytest.mark.parametrize("rows,C", [(300, 320), (77, 640), (1024, 1280)])
 def test_layernorm(sdlib, rows, C):
     g = torch.Generator().manual_seed(rows)
