@@ -211,7 +211,7 @@ def end_to_end(model, args, dev):
     return best
 
 
-PROFILE_ROUND = "round3"
+PROFILE_ROUND = "round4"
 TRAFFIC_FILE = f"profiles/{PROFILE_ROUND}_conv_traffic.json"
 PMC_FILE = f"profiles/{PROFILE_ROUND}_pmc_forward.json"
 TRAFFIC_SOURCE = (f"{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_traffic.sh over "

@@ -55,7 +55,7 @@ __device__ __forceinline__ void dma16(rsrc_t r, void* lds_wave_base, int voff, i
 // Two instantiations instead of one kernel with every feature live: the union ran out of scalar registers (11 buffer
 // resources = 44 SGPRs) and spilled them into vector lanes.  Buffer resources only for the streams that need the range
 // check or carry most of the traffic (X, X2, W, C / KV, R); the small side tensors use scalar-base global accesses.
-// NP = number of LayerNorm partials per row (4, 8, 16), 0 = the LN = false kernel.  GEGLU: the 256 x 256 tile on 8 waves
+// NP = number of LayerNorm partials per row (2, 4, 8, 16), 0 = the LN = false kernel.  GEGLU: the 256 x 256 tile on 8 waves
 // (one workgroup per CU: half the LDS-fill bytes per flop of 128 x 128), weight rows packed [16 value | 16 gate] per 32
 // columns, output N / 2 columns of value * gelu(gate); LayerNorm fold or plain bias, nothing else.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, bool GEGLU>
@@ -165,6 +165,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
     int g = 0;                     // running K-tile count: LDS buffer parity
     bool stores_pending = false;
     stage(0, 0);
+#ifdef SD_PRIO_TEST
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     while (true) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)
@@ -473,7 +476,7 @@ bool sd_gemm_lean_applicable(const GemmArgs& a, int epi) {
     if ((a.stats || a.rowstats || a.ln_rs || a.hm_C) && a.M % (epi ? 256 : 128) != 0) return false;
     if (a.ln_rs) {      // the LN = true instantiations: one K segment, c1 / c2, 4 / 8 / 16 partials, no producer side
         if (a.R || a.bias2 || !a.bias || !a.ln_c1 || a.X2 || a.K1 != a.K || a.stats || a.rowstats) return false;
-        if (a.ln_np != 4 && a.ln_np != 8 && a.ln_np != 16) return false;
+        if (a.ln_np != 2 && a.ln_np != 4 && a.ln_np != 8 && a.ln_np != 16) return false;
     }
     if (epi == 1 && (a.R || a.bias2 || a.X2 || a.K1 != a.K || a.stats || a.rowstats || a.hm_C)) return false;
     if (a.hm_C) {       // head-major K / V: on the q|k|v projection, which is a LayerNorm-fold consumer in the UNet plan
@@ -520,11 +523,13 @@ int sd_launch_gemm_lean(const GemmArgs& g, int epi, int rows, hipStream_t stream
     }
     if (epi == 1) {
         if (!g.ln_rs) return launch_lean<256, 256, 4, 2, 0, true>(a, stream);
-        return g.ln_np == 4 ? launch_lean<256, 256, 4, 2, 4, true>(a, stream)
+        return g.ln_np == 2 ? launch_lean<256, 256, 4, 2, 2, true>(a, stream)      // (2 partials: the fused cross-attention's, one slice)
+             : g.ln_np == 4 ? launch_lean<256, 256, 4, 2, 4, true>(a, stream)
              : g.ln_np == 8 ? launch_lean<256, 256, 4, 2, 8, true>(a, stream) : launch_lean<256, 256, 4, 2, 16, true>(a, stream);
     }
     if (g.ln_rs)
-        return g.ln_np == 4 ? launch_lean<128, 160, 2, 2, 4, false>(a, stream)
+        return g.ln_np == 2 ? launch_lean<128, 160, 2, 2, 2, false>(a, stream)
+             : g.ln_np == 4 ? launch_lean<128, 160, 2, 2, 4, false>(a, stream)
              : g.ln_np == 8 ? launch_lean<128, 160, 2, 2, 8, false>(a, stream) : launch_lean<128, 160, 2, 2, 16, false>(a, stream);
     return rows == 64 ? launch_lean<64, 160, 2, 2, 0, false>(a, stream) : launch_lean<128, 160, 2, 2, 0, false>(a, stream);
 }

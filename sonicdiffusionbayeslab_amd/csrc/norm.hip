@@ -514,7 +514,7 @@ size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups) {
 
 int sd_groupnorm_nsplit(int B, int HW) {
     // enough blocks to cover 256 CUs several times over, but >= 8 pixels per block
-    int n = (2048 + B - 1) / B;
+    int n = (2048 + B - 1) / B;      // (512 .. 4096 target blocks measure the same within 2 %, round 4)
     if (n > HW / 8) n = HW / 8;
     if (n < 1) n = 1;
     if (n > 256) n = 256;

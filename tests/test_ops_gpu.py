@@ -395,7 +395,8 @@ def test_gemm_lean_layernorm_fold_and_headmajor_kv(sdlib, B, tokens, C, mean):
                 assert torch.equal(kv[which], want)
 
 
-@pytest.mark.parametrize("M,C,fold", [(512, 320, True), (256, 640, True), (256, 1280, True), (512, 320, False), (300, 640, False)])
+@pytest.mark.parametrize("M,C,fold", [(512, 320, True), (256, 640, True), (256, 1280, True), (512, 320, False), (300, 640, False),
+                                      (512, 320, 2)])      # 2 partials per row: the fused cross-attention's at the 64x64 level
 def test_gemm_lean_geglu_kernel_is_bit_identical_to_the_general_kernel(sdlib, M, C, fold):
     """The GEGLU projection (ff.net.0.proj, N = 8 C packed [16 value | 16 gate]) on the lean 256 x 256 kernel of
     csrc/gemm_lean.hip -- with the LayerNorm fold (4 / 8 / 16 row partials: norm3 -> GEGLU as the plan runs it) and with a
@@ -412,7 +413,7 @@ def test_gemm_lean_geglu_kernel_is_bit_identical_to_the_general_kernel(sdlib, M,
         gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
         z = F.layer_norm(h, (C,), gamma, beta, 1e-5) @ r16(w).t() + b
         wg, c1, c2 = fold_layernorm(w[idx], gamma, beta, b[idx])
-        parts = 2 * (C // 160)
+        parts = 2 * (C // 160) if fold is True else int(fold)
         hh = h.view(M, parts, C // parts)
         rs = dev(torch.stack([hh.sum(2), (hh * hh).sum(2)], dim=2).permute(1, 0, 2).contiguous())
         hd, wd, c1d, c2d = dev(h, torch.bfloat16), dev(wg, torch.bfloat16), dev(c1), dev(c2)
