@@ -175,6 +175,51 @@ def gpu_free_running(model, cfg, args, dev, n_steps=12):
     return traj
 
 
+def full_length_parity(model, cfg, sd, args, dev):
+    """The headline's own loop at FULL length -- 50 of 50 DDIM steps, CFG 7.5, 64x64 latents, batch 1 -- on the GPU path, against
+    the oracle's trajectory COMMITTED as a fixture (tests/golden/loop_golden_64.npz, generated by
+    tests/golden/make_loop_golden.py: data, not code -- no oracle runs here).  The inputs are re-drawn from the fixture's
+    seed and must be bit-identical to the stored ones; the fixture must belong to this run's synthetic weights.  Returns
+    None with a reason when it does not apply."""
+    import hashlib
+    import numpy as np
+    from sonicdiffusionbayeslab_amd.registry import schedulers_registry
+    from sonicdiffusionbayeslab_amd.schedulers import PNDMConfigStub
+    path = os.path.join(ROOT, "tests", "golden", "loop_golden_64.npz")
+    if not (os.path.exists(path) and cfg.sample_size == 64 and args.ddim_steps == 50 and args.dtype == "bf16"):
+        return {"skipped": "needs the committed fixture, 64x64 latents, 50 DDIM steps, bf16"}
+    z = np.load(path)
+    h = hashlib.sha256()
+    for k in ("conv_in.weight", "mid_block.resnets.0.conv1.weight", "up_blocks.3.attentions.2.transformer_blocks.0.ff.net.2.weight",
+              "conv_out.bias"):
+        h.update(sd[k].detach().float().contiguous().numpy().tobytes())
+    if h.hexdigest()[:16] != str(z["weights_fingerprint"]):
+        return {"skipped": "the fixture was generated for other synthetic weights"}
+    g = torch.Generator().manual_seed(29)                      # tests/util.py::synth_inputs(cfg, 1, seed=29)
+    lat = torch.randn((1, cfg.in_channels, 64, 64), generator=g)
+    pe = torch.randn((1, cfg.context_len, cfg.cross_attention_dim), generator=g)
+    ne = torch.randn((1, cfg.context_len, cfg.cross_attention_dim), generator=g)
+    if not torch.equal(lat, torch.as_tensor(z["ddim50/init"])):
+        return {"skipped": "the re-drawn inputs differ from the fixture's"}
+    s = schedulers_registry["ddim_scheduler"].from_config(PNDMConfigStub().config)
+    s.set_timesteps(50, device=dev)
+    model.unet.set_deepcache(-1)
+    model.unet.set_context(torch.cat([ne, pe]).to(dev))
+    x, rows = lat.to(dev), {}
+    for i, t in enumerate(s._timesteps_list):
+        eps = model.unet.forward_latents(x, 2, float(t))
+        x, _ = s.step_fused(eps, 7.5, x, t, cfg=True)
+        if (i + 1) % 10 == 0:
+            ref = torch.as_tensor(z[f"ddim50/step{i + 1}"])
+            got = x.float().cpu()
+            d = got - ref
+            rows[f"after_{i + 1}_steps"] = {"rel_l2": (d.norm() / ref.norm()).item(), "max_abs": d.abs().max().item(),
+                                            "cosine": (got.flatten() @ ref.flatten() / (got.norm() * ref.norm())).item()}
+    return {"against": "the fp32 CPU oracle's trajectory committed as tests/golden/loop_golden_64.npz (oracle/ = this build's "
+                       "restatement: PARITY UNPINNED -- DESIGN.md 2)",
+            "what": "free-running latents of the headline loop at full length: 50 of 50 DDIM steps, CFG 7.5, 64x64, batch 1", **rows}
+
+
 def end_to_end(model, args, dev):
     """next to the loop-only number, the time of one whole call from prompt STRINGS to decoded
     512x512 images -- CLIP text encoding (libsdhip text tower, seeded synthetic ViT-L/14-shaped weights, merge-free
@@ -522,6 +567,8 @@ def main():
         traj = gpu_free_running(model, cfg, args, dev) if args.dtype == "bf16" and args.scheduler == "ddim" else None
         res["cpu_baseline"], parity = cpu_baseline(cfg, sd, args, traj)
         res["config"]["parity"] = parity
+    if rank == 0 and world == 1 and is_headline:
+        res["config"]["parity_full_length"] = full_length_parity(model, cfg, sd, args, dev)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -246,9 +246,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
     // (+5 % time), or only for waves 4-7, the SIMD partners of waves 0-3, as two straight-line loops (+9 %) or with
     // wave-uniform branches inside the taps (+21 %: spills reloaded in the loop behind vmcnt(0)).  The fragment-read wait
     // and the DMA issue after the barrier are therefore NOT what idles the matrix pipe for half of a tap.
-#ifdef SD_PRIO_TEST
-    if (NWV == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     while (true) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)

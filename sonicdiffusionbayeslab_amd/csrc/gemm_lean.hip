@@ -165,9 +165,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
     int g = 0;                     // running K-tile count: LDS buffer parity
     bool stores_pending = false;
     stage(0, 0);
-#ifdef SD_PRIO_TEST
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     while (true) {
 #pragma unroll
         for (int a = 0; a < TN; ++a)

@@ -164,9 +164,6 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     const int arow = hg * HKEYS * 64;
     const float c = 1.4426950408889634f;
 
-#ifdef SD_PRIO_TEST
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     if (!(V & 4)) __builtin_amdgcn_s_waitcnt(0);          // bias loads + LDS writes retired
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) piece1(0, i, smem, true);

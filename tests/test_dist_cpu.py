@@ -21,7 +21,7 @@ def _worker(rank, world, port, gb, q):
     lo, hi = shard_range(gb, rank, world)
     local = lat[lo:hi] * 2.0 + 1.0          # stand-in for the per-rank sampling result
     full = gather_latents(local, world, gb)
-    q.put((rank, full))
+    q.put((rank, full.numpy()))          # by value: a torch tensor travels as an fd the consumer must fetch while this rank lives
     dist.barrier()
     dist.destroy_process_group()
 
@@ -32,7 +32,7 @@ def _run(gb):
     port = _free_port()
     ps = [ctx.Process(target=_worker, args=(r, 2, port, gb, q)) for r in range(2)]
     [p.start() for p in ps]
-    outs = dict(q.get(timeout=120) for _ in range(2))
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(2))}
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     return outs
@@ -89,7 +89,8 @@ class _StubPipeline:
 def _harness_worker(rank, world, port, lcm, nprompts, batch, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SD_DIST_BACKEND="gloo")
-    q.put((rank,) + _harness_run(lcm, nprompts, batch))
+    out, t, calls = _harness_run(lcm, nprompts, batch)
+    q.put((rank, out.numpy(), t, calls))         # by value (see _worker)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -125,7 +126,7 @@ def _harness_world(world, lcm, nprompts, batch=5):
     port = _free_port()
     ps = [ctx.Process(target=_harness_worker, args=(r, world, port, lcm, nprompts, batch, q)) for r in range(world)]
     [p.start() for p in ps]
-    outs = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
+    outs = {r[0]: (torch.from_numpy(r[1]),) + tuple(r[2:]) for r in (q.get(timeout=300) for _ in range(world))}
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     return outs

@@ -60,7 +60,7 @@ def _worker(rank, world, port, cases, q, backend="gloo", force=False):
     for idx, (config_name, nprompts, batch, overrides) in enumerate(cases):
         out, t = _run_method(config_name, nprompts, batch, overrides)
         assert dist.is_initialized() and dist.get_backend() == backend and dist.get_world_size() == world
-        q.put((rank, idx, out.cpu(), t))
+        q.put((rank, idx, out.cpu().numpy(), t))       # by value: no fd hand-off that needs this rank alive
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,7 +86,7 @@ def world2_runs():
     got = {}
     for _ in range(2 * len(CASES)):
         rank, idx, out, t = q.get(timeout=600)
-        got[(rank, idx)] = (out, t)
+        got[(rank, idx)] = (torch.from_numpy(out), t)
     [p.join(120) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     return want, got
@@ -118,6 +118,7 @@ def test_rccl_world1_rehearsal_of_the_gather_path():
     p = ctx.Process(target=_worker, args=(0, 1, _free_port(), [("ddim_config.yaml", 3, 3, None)], q, "nccl", True))
     p.start()
     rank, _, got, t = q.get(timeout=600)
+    got = torch.from_numpy(got)
     p.join(120)
     assert p.exitcode == 0
     assert got.shape == want.shape and torch.equal(got, want) and t > 0
