@@ -35,7 +35,8 @@ for kind in kinds:
     grp = collections.OrderedDict()
     for i, a in acc.items():
         if a["kind"] == kind:
-            g = grp.setdefault((a["M"], a["N"], a["K"]), dict(n=0, ms=0.0, gf=a["gf"], mb=a["mb"]))
+            key = (a["M"], a["N"], a["K"]) if a["M"] else (int(round(a["mb"] * 1e3)), 0, 0)     # norms carry no M N K: KB moved
+            g = grp.setdefault(key, dict(n=0, ms=0.0, gf=a["gf"], mb=a["mb"]))
             g["n"] += 1; g["ms"] += a["ms"]
     print(f"kind {kind}: M N K | launches | us each | total ms | TFLOP/s | GB/s (algorithmic)")
     for (M, N, K), g in sorted(grp.items(), key=lambda kv: -kv[1]["ms"]):
