@@ -84,16 +84,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int V>
 __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane0 = tid & 63;
-    const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb = wave & 3, hg = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
     const int C = p.C;
-    // PERSISTENT over token blocks (round 4): the grid is min(items, CUs) workgroups and workgroup b takes the items
-    // b, b + gridDim.x, ...; a CU holds ONE workgroup of this kernel (157 KiB of LDS), so with a workgroup per item every
-    // item paid the dispatch of a fresh workgroup behind the slowest wave of the previous one plus the latency of its first
-    // operand tile with nothing else resident (measured: 14 % of the launch outside the workgroups' own stamps).  The next
-    // item's first two K tiles are requested from inside the last phase-2 stage, before the epilogue.
-    const int nitems = (int)(p.M / TOK);
-    int it = blockIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of token tiles,
+    // i.e. whole samples, so that the workgroups that stream one sample's A^T / Bw share one L2.  Speed only.
+    int wg = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, rr = nblk & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const long m0 = (long)wg * TOK;
+    const int sample = (int)(m0 / p.rows_per_sample);
+    const char* At = (const char*)p.At + (long)sample * KEYS * C * 2;
+    const char* Bw = (const char*)p.Bw + (long)sample * C * KEYS * 2;
     const long rowbytes = (long)C * 2;
     const int KT = C / 32;
     const int NPall = C / 64, nsl = gridDim.y;         // channel-tile PAIRS of this slice
@@ -101,62 +107,40 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
 
     // diagnostic phase stamps (only with a stamp buffer: tools/xattn_stamps.py); never read by the kernel
     auto stamp = [&](int i) {
-        if (p.stamps && tid == 0) p.stamps[((long)blockIdx.y * nitems + it) * 8 + i] = __builtin_amdgcn_s_memtime();
+        if (p.stamps && tid == 0) p.stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + i] = __builtin_amdgcn_s_memtime();
     };
-    // to_out bias -> LDS, once per workgroup.  V & 4: by LDS-DMA (C floats = C / 256 one-KiB pieces, waves 0 .. C / 256 - 1 one
-    // piece each; C is a multiple of 64, a partial last piece re-reads the vector's tail -- clamped source, identical bytes land
-    // in the slack behind sbias[C]); else ordinary loads, the kernel's only ones, retired before any DMA is in flight.
+    stamp(0);
+    // to_out bias -> LDS.  V & 4: by LDS-DMA (C floats = C / 256 one-KiB pieces, waves 0 .. C / 256 - 1 one piece each; C is a
+    // multiple of 64, a partial last piece re-reads the vector's tail -- clamped source, identical bytes land in the slack
+    // behind sbias[C]); else ordinary loads, the kernel's only ones, retired before any DMA is in flight.
     float* sbias = (float*)(smem + BIASOFF);
     if (V & 4) {
-        if (wave0 * 256 < C) {
-            const int i = min(wave0 * 256 + lane0 * 4, C - 4);
-            glds16(p.bias + i, (char*)sbias + wave0 * 1024);
+        if (wave * 256 < C) {
+            const int i = min(wave * 256 + lane * 4, C - 4);
+            glds16(p.bias + i, (char*)sbias + wave * 1024);
         }
     } else {
         for (int i = tid; i < C; i += 512) sbias[i] = p.bias[i];
-        __builtin_amdgcn_s_waitcnt(0);                    // bias loads + LDS writes retired
     }
-
-    for (;;) {          // items of this workgroup
-    // Everything an item derives from (lane, wave) is derived again per item from copies the optimiser cannot see through:
-    // hoisted out of the item loop these ~40 values would be live across phase 1 / the softmax, where the 160 accumulators
-    // leave 14 spare registers (measured: 14 VGPRs + 101 SGPRs spilled).
-    int lane = lane0, wave = wave0;
-    asm volatile("" : "+v"(lane));
-    asm volatile("" : "+s"(wave));
-    const int tb = wave & 3, hg = wave >> 2;
-    const int r = lane & 31, h = lane >> 5;
-    const int prow = lane >> 2;
-    const int sch = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (gridDim.x is the item count or a multiple of 8, so
-    // item v runs on XCD v & 7); give each XCD a contiguous run of token tiles, i.e. whole samples, so that the workgroups
-    // that stream one sample's A^T / Bw share one L2.  Speed only.
-    // A^T and Bw are stored TILED (set_context / sd_launch_retile32): [K tile][640 rows][64 B] and [channel tile][32-slot
-    // slice][32 rows][64 B], so an operand piece is one contiguous KiB = 8 full cache lines (16 half lines at the row
-    // stride cost twice the address-unit time and twice the L2 requests)
-    auto item_row0 = [&](int v) {         // first token of item v
-        const int q = nitems >> 3, rr = nitems & 7, xcd = v & 7, idx = v >> 3;
-        const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-        return (long)wg * TOK;
-    };
-    const long m0 = item_row0(it);
-    const int sample = (int)(m0 / p.rows_per_sample);
-    const char* Bw = (const char*)p.Bw + (long)sample * C * KEYS * 2;
-    const char* aptr = (const char*)p.At + (long)sample * KEYS * C * 2 + (long)(16 * wave + prow) * 64 + sch;   // A piece i (0..4): + i * 128 rows
-    const char* xptr = (const char*)p.X + (m0 + 16 * wave + prow) * rowbytes + sch;                             // piece 5: X rows 16 wave ..
-    const char* rptr = (const char*)p.R + (m0 + 16 * wave + prow) * rowbytes + sch;
 
     // ---- LDS-DMA pieces (16 rows x 64 B; lane -> row lane >> 2, chunk lane & 3, swizzled on the source) ----
     // `real` = false: nothing left to fetch -- the piece still issues (constant DMA counts, no branch) but reads 16 hot bytes
+    const int prow = lane >> 2;
+    const int sch = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
     const char* dummy = (const char*)p.bias;
-    auto piece1p = [&](const char* ap, const char* xp, int kt, int i, char* st, bool real) {
-        const char* src = i < 5 ? ap + ((long)kt * KEYS + i * 128) * 64 : xp + kt * 64;
+    // A^T and Bw are stored TILED (set_context / sd_launch_retile32): [K tile][640 rows][64 B] and [channel tile][32-slot
+    // slice][32 rows][64 B], so an operand piece is one contiguous KiB = 8 full cache lines (16 half lines at the row
+    // stride cost twice the address-unit time and twice the L2 requests)
+    const char* aptr = At + (long)(16 * wave + prow) * 64 + sch;                         // A piece i (0..4): + i * 128 rows
+    const char* xptr = (const char*)p.X + (m0 + 16 * wave + prow) * rowbytes + sch;      // piece 5: X rows 16 wave ..
+    auto piece1 = [&](int kt, int i, char* st, bool real) {
+        const char* src = i < 5 ? aptr + ((long)kt * KEYS + i * 128) * 64 : xptr + kt * 64;
         glds16(real ? src : dummy, st + (i < 5 ? wave + 8 * i : 40 + wave) * 1024);
     };
-    auto piece1 = [&](int kt, int i, char* st, bool real) { piece1p(aptr, xptr, kt, i, st, real); };
     // phase 2, stage s = 2 * pair + kh: Bw piece q = wave + 8 i (i < 5): tile q / 20 of the pair, sub-tile (q % 20) >> 1 of
     // the 10 sub-tiles (32 key slots = 64 B) of key half kh, rows 16 (q & 1) .. + 15; piece 5: residual rows
     // 16 (wave & 7).. of tile kh of the pair (so one pair's residual arrives with its two stages)
+    const char* rptr = (const char*)p.R + (m0 + 16 * wave + prow) * rowbytes + sch;
     auto piece2 = [&](int pi, int kh, int i, char* st, char* rst, bool real) {
         const char* src;
         char* dst;
@@ -180,15 +164,12 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     const int arow = hg * HKEYS * 64;
     const float c = 1.4426950408889634f;
 
-    if (it == (int)blockIdx.x) {        // first item: its K tiles 0 and 1 (later items: requested by the previous item's last stage)
+    if (!(V & 4)) __builtin_amdgcn_s_waitcnt(0);          // bias loads + LDS writes retired
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) piece1(0, i, smem, true);
+    for (int i = 0; i < PIECES; ++i) piece1(0, i, smem, true);
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) piece1(1, i, smem + STAGE1, KT > 1);
-    }
-    stamp(0);
-    const int next = it + (int)gridDim.x;
-    const bool has_next = next < nitems;
+    for (int i = 0; i < PIECES; ++i) piece1(1, i, smem + STAGE1, KT > 1);
+
     // =============================== phase 1: S^T = A^T . X^T (this wave's 4 heads) ===============================
     // V & 16: no zeroing of the 160 accumulators -- the first K tile's first k-step multiplies onto a constant-zero C operand
     f32x16 S[NKT];
@@ -446,21 +427,6 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kh == 1 && s == NS - 1) {
-            // every wave has read its last fragments: the stages are free.  The next item's K tiles 0 and 1 (phase-1 stages
-            // 0 and 1 = bytes [0, 96 KiB); the epilogue below reads the residual ring and the bias behind 120 KiB) are
-            // requested now and land under the epilogue; the last item of a workgroup issues dummies (constant counts).
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const long n0 = item_row0(has_next ? next : it);
-            const int nsample = (int)(n0 / p.rows_per_sample);
-            const char* na = (const char*)p.At + (long)nsample * KEYS * C * 2 + (long)(16 * wave + prow) * 64 + sch;
-            const char* nx = (const char*)p.X + (n0 + 16 * wave + prow) * rowbytes + sch;
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) piece1p(na, nx, 0, i, smem, has_next);
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) piece1p(na, nx, 1, i, smem + STAGE1, has_next && KT > 1);
-        }
         if (kh == 1) {
             // ---- epilogue (LDS operands only): lane holds channels 32 j + 8 g + 4 h + (0..3), g = 0..3, of its token ----
             const int j = 2 * pi + hg;
@@ -502,9 +468,6 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
         if (h == 0) *(f32x2_t*)(p.rowstats + (((long)blockIdx.y * 2 + hg) * p.M + trow) * 2) = f32x2_t{ysum, ysq};
     }
     stamp(5);
-    if (!has_next) break;
-    it = next;
-    }
 }
 
 }  // namespace
@@ -542,21 +505,7 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
     // SD_XATTN_VARIANT=0: the round-2 kernel (A/B); 15 = the first four round-3 changes; default 31 = all round-3 changes (measured one by one on one box, 64x64
     // launch of the bench: 72.2 us -> bias by DMA 70.9 -> + phase-1 carried group 69.9 -> + phase 2 68.5 -> + static P 68.0)
     static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 31;
-    // persistent grid (round 4): one workgroup per CU loops over the token blocks; SD_XATTN_PERSIST=0 launches a workgroup
-    // per block as rounds 1-3 did (same kernel, same results: the item loop then runs once)
-    const char* penv = getenv("SD_XATTN_PERSIST");          // read per call: the tests compare the two launch forms in one process
-    const bool persist = !(penv && atoi(penv) == 0);
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        SD_CHECK_HIP(hipGetDevice(&dev));
-        SD_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        ncu = prop.multiProcessorCount & ~7;          // a multiple of 8: item v stays on XCD v & 7 (the kernel's order)
-        if (ncu < 8) ncu = 8;
-    }
-    const int items = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
-    const int wgs = persist && items > ncu ? ncu : items;
+    const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
     if (variant == 0) hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     else if (variant == 15) hipLaunchKernelGGL(xattn_fused_kernel<15>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     else hipLaunchKernelGGL(xattn_fused_kernel<31>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);

@@ -26,7 +26,7 @@ traffic)
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_traffic/$c -- python $R/tools/forward_once.py > $O/pmc_traffic_$c.log 2>&1 || fail $O/pmc_traffic_$c.log; done
   (cd $R && python tools/pmc_traffic.py gpurun_out/pmc_traffic "conv_halo_kernel" gpurun_out/r4_conv_traffic.json) ;;
 attn)    # 64x64 self-attention alone: round-2 kernel vs the round-3 one (SD_ATTN_VARIANT 0 / 7)
-  bash $R/tools/r4_attn_pmc.sh 0 7 ;;
+  bash $R/tools/r3_attn_pmc.sh 0 7 ;;
 stats)
   rm -rf $O/stats
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs > $O/stats_bench.log 2>&1 || fail $O/stats_bench.log
