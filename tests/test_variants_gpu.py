@@ -39,7 +39,7 @@ def test_two_schedulers_ddim_to_dpm(env, type_switch, n_first, switch):
     model = _make(env, "stable_diffusion_model_two_schedulers")
     model.scheduler_first = _sched("ddim_scheduler")
     model.scheduler_second = _sched("dpm_solver_scheduler", **DPM_KW)
-    lat, pe, ne = synth_inputs(cfg, 2, seed=41)
+    lat, pe, ne = synth_inputs(cfg, 1, seed=41)
     out, secs, x0s = model(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, guidance_scale=7.5,
                            num_inference_steps_first=n_first, num_inference_steps_second=n_first,
                            num_step_switch=switch, type_switch=type_switch, output_type="latent")
@@ -77,7 +77,7 @@ def test_skip_timesteps(env, sched, kw, oracle):
     cfg, sd = env
     model = _make(env, "stable_diffusion_model_skip_timesteps")
     model.scheduler = _sched(sched, **kw)
-    lat, pe, ne = synth_inputs(cfg, 2, seed=47)
+    lat, pe, ne = synth_inputs(cfg, 1, seed=47)
     n, skip = 7, [2, 5]
     out, _, x0s = model(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, guidance_scale=7.5,
                         num_inference_steps=n, skip_timesteps=skip, output_type="latent")
