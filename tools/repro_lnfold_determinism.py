@@ -1,5 +1,9 @@
+"""Run-to-run determinism of the LayerNorm-folded 64x64 q|k|v projection (M 65536, N 960, K 320): 7 launches per seed,
+every output compared with the element-wise median; prints what a deviating element looks like (round 4: the packed-FMA form
+of the fold gave ~1 event per 40 launches -- one accumulator register of lanes 48-63 equal to c2 alone; profiles/round4_notes.md).
+The product build reports "found 0".  SD_AMD_LIB=<other build> NSEED=12 python tools/repro_lnfold_determinism.py"""
 import os, sys, math, torch, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sonicdiffusionbayeslab_amd import _lib as L
 lib = C.CDLL(os.environ.get("SD_AMD_LIB", L.LIB_PATH))
 fn = lib.sd_op_gemm_ln; fn.restype, fn.argtypes = L._SIGS["sd_op_gemm_ln"]
