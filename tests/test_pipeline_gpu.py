@@ -157,6 +157,9 @@ def test_lcm_loop_no_cfg(env):
     assert err < FREE_TOL and cs > FREE_COS
 
 
+_PLAIN = {}
+
+
 @pytest.mark.parametrize("interval,branch", [(3, 0), (2, 0), (2, 1), (3, 4)])
 def test_deepcache_loop(env, interval, branch):
     """DeepCacheSDHelper call pattern of src/experiments/deep_cache.py:24-29,58; the skip-step plan
@@ -177,7 +180,9 @@ def test_deepcache_loop(env, interval, branch):
         helper.disable()
     dc = DeepCacheState(cache_interval=interval, cache_branch_id=branch, enabled=True)
     ref, _, _, _ = _oracle_loop(cfg, sd, DDIMOracle(), pe, ne, lat, 7, 7.5, deepcache=dc)
-    plain, _, _, _ = _oracle_loop(cfg, sd, DDIMOracle(), pe, ne, lat, 7, 7.5)
+    if "plain" not in _PLAIN:           # the same inputs for every (interval, branch): one oracle loop without the cache
+        _PLAIN["plain"] = _oracle_loop(cfg, sd, DDIMOracle(), pe, ne, lat, 7, 7.5)[0]
+    plain = _PLAIN["plain"]
     err, cs = rel_l2(out.images, ref), cosine(out.images, ref)
     print(f"DeepCache N={interval} branch={branch}: rel-L2 {err:.3e} cos {cs:.5f}; cached-vs-plain {rel_l2(ref, plain):.3e}")
     assert err < FREE_TOL and cs > FREE_COS
