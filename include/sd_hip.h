@@ -210,6 +210,13 @@ int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias,
  * needs Hin * Win % 128 == 0.  Y = [B, 2 Hin, 2 Win, Cout]. */
 int sd_op_conv3x3_upsample_subpixel(void* stream, const void* X, const void* W4, const float* bias, void* Y, int B, int Hin,
                                     int Win, int Cin, int Cout);
+/* The same followed by the GroupNorm(+SiLU) of the next resnet, as the plan runs the pair: the conv epilogue delivers the
+ * per-64-row-block channel statistics (row order (sample, phase, low-res pixel)) and the GroupNorm skips its statistics pass.
+ * Where (pixel tiles x 4 phases x channel tiles) >= 256 the conv runs on the halo kernel's 4-tap mode (csrc/conv_halo.hip,
+ * SD_SUBPIX_HALO=0: the implicit-GEMM kernel; bit-identical).  Y: conv output, Yn: normalised output. */
+int sd_op_conv3x3_upsample_subpixel_groupnorm(void* stream, const void* X, const void* W4, const float* bias, void* Y, int B,
+                                              int Hin, int Win, int Cin, int Cout, const float* gamma, const float* beta,
+                                              void* Yn, int groups, float eps, int silu);
 int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
                     const float* beta, void* y, int B, int HW, int groups, float eps, int silu);
 /* conv3x3 (stride 1) -> GroupNorm(+SiLU) the way the forward plan runs every resnet's conv -> norm pair

@@ -86,6 +86,7 @@ _SIGS = {
     "sd_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "sd_op_conv3x3_ablate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "sd_op_conv3x3_upsample_subpixel": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "sd_op_conv3x3_upsample_subpixel_groupnorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i]),
     "sd_op_groupnorm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "sd_op_conv3x3_groupnorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i]),
     "sd_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),

@@ -62,9 +62,19 @@ __device__ __forceinline__ int swz_of(int row, int dt) { return dt ? (((row >> 1
 // One wave per SIMD has no partner to hide the barrier and the first fragment reads of a tap, so the second k-step's
 // MFMAs of a tap are issued after the NEXT tap's barrier from fragments carried in registers (same per-accumulator order
 // as the plain loop: bit-identical).
-template <int DT, int DIAG = 0, int NWV = 8>
+//
+// SUB = 1 (round 4): the nearest-2x upsample + 3x3 conv as FOUR 2x2 convs on the low-res input (GemmArgs::subpix; 4/9 of the
+// multiply-adds).  The tile grid runs over the low-res pixels of ONE output phase (py, px); a work item is (pixel tile,
+// phase, channel tile), a channel slice has FOUR taps -- halo offsets (py + ty - 1, px + tx - 1), ty, tx in {0, 1} -- with the
+// phase's own weights ([4 phases][Cout][Cin/64][4 taps][64]), and the epilogue scatters row (b, y, x) to output pixel
+// (2 y + py, 2 x + px).  The halo of a slice is still 7 pieces per wave, now spread 2-2-2-1 over the four taps (56 KiB of halo
+// + 4 x 20 KiB of W per slice against the implicit-GEMM kernel's 4 x (32 + 20) KiB).  Same K order (slice, tap, channel) and
+// the same 16x16x32 accumulation chains as the implicit-GEMM form: bit-identical results.
+template <int DT, int DIAG = 0, int NWV = 8, int SUB = 0>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(const GemmArgs p) {
     static_assert(NWV == 8 || (NWV == 4 && DT == 0), "4-wave layout: bf16 only");
+    static_assert(!SUB || (DT == 0 && DIAG == 0 && NWV == 8), "sub-pixel upsampler: bf16, 8 waves");
+    constexpr int NTAP = SUB ? 4 : 9;             // taps = K tiles per channel slice
     constexpr int NT = NWV * 64;
     constexpr int WMW = NWV == 8 ? 4 : 2;         // waves along the pixels
     constexpr int TM = BM / WMW / 16, WTM = TM * 16;
@@ -86,15 +96,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
         work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int nwork = ntiles * p.splitk;
+    const int nwork = ntiles * (SUB ? 4 : p.splitk);
     if (work >= nwork) return;
     const int S = (p.Cin * ESZ) >> 7;
+    const int Mrows = SUB ? p.M >> 2 : p.M;      // rows of the tile grid (SUB: the low-res pixels, = the rows of one phase)
 
     // tile geometry: BM / PIX pieces of RW whole OUTPUT rows (more than one piece only when an image has
     // fewer than 256 pixels).  With the fused nearest-2x upsample (p.up = 1) the halo lives in the
     // low-resolution input: (RW / 2 + 2) x (Win + 2) slots, and a tap reads slot ((y + dy - 1) >> 1, ...).
-    const int up = p.up;
-    const int Ho = p.Hout, Wo = p.Wout, HWo = Ho * Wo;
+    const int up = SUB ? 0 : p.up;
+    const int Ho = SUB ? p.Hin : p.Hout, Wo = SUB ? p.Win : p.Wout, HWo = Ho * Wo;
     const int RW = min(Ho, BM / Wo);
     const int PW = p.Win + 2, PP = ((RW >> up) + 2) * PW;
     const int PIX = RW * Wo;                     // output pixels per piece
@@ -135,23 +146,32 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
     auto wpiece = [&](int i) { return NWV == 4 ? wave + 4 * i : (i < 2 ? wave + 8 * i : (wave < 4 ? wave + 16 : wave + 8)); };
 
     // ---- per-item state: tile origin, K range, source offsets -------------------------------------------
-    int split = 0, m0 = 0, n0 = 0, s_begin = 0, s_end = 0;
+    int split = 0, m0 = 0, n0 = 0, s_begin = 0, s_end = 0, phase = 0;
     unsigned hoff[HPIECES];                      // byte offsets into X; NOSRC = zero page
     unsigned woffs[WPW];                         // byte offsets into W
     auto setup = [&](int w) {
-        split = w / ntiles;
-        const int t = w - split * ntiles;
-        const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+        int tile_n, tile_m;
+        if (SUB) {           // n fastest, then the four phases of a pixel tile (they share its halo), no split-K
+            tile_n = w % p.tiles_n;
+            const int q = w / p.tiles_n;
+            phase = q & 3;
+            tile_m = q >> 2;
+            split = 0; s_begin = 0; s_end = S;
+        } else {
+            split = w / ntiles;
+            const int t = w - split * ntiles;
+            tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+            s_begin = (int)((long)S * split / p.splitk);
+            s_end = (int)((long)S * (split + 1) / p.splitk);
+        }
         m0 = tile_m * BM;
         n0 = tile_n * BN;
-        s_begin = (int)((long)S * split / p.splitk);
-        s_end = (int)((long)S * (split + 1) / p.splitk);
 #pragma unroll
         for (int j = 0; j < HPIECES; ++j) {
             const int mp = m0 + (hrel[j] & 3) * PIX;                   // first output pixel of the piece
             const int b = mp >> lgHW;
             const int ybase = (mp & (HWo - 1)) >> (lgW + up);          // its first input row
-            const bool ok = hrel[j] != HREL_ZERO && mp < p.M && !((hrel[j] & 4) && ybase == 0) &&
+            const bool ok = hrel[j] != HREL_ZERO && mp < Mrows && !((hrel[j] & 4) && ybase == 0) &&
                             !((hrel[j] & 8) && ybase + RWin == p.Hin);
             const unsigned base = (unsigned)(((long)b * p.Hin + ybase) * p.Win * p.Cin * ESZ);
             hoff[j] = ok ? base + (unsigned)(hrel[j] & ~15) : NOSRC;
@@ -161,19 +181,26 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
             const int pc = wpiece(i);
             const int n = n0 + pc * 8 + (lane >> 3);
             const int c = (lane & 7) ^ swz_of(lane >> 3, DT);
-            woffs[i] = n < p.N ? (unsigned)((long)n * p.ldw * ESZ + (c << 4)) : NOSRC;
+            woffs[i] = n < p.N ? (unsigned)(((SUB ? (long)phase * p.w_batch_stride : 0l) + (long)n * p.ldw) * ESZ + (c << 4)) : NOSRC;
         }
     };
     auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch (zero page), keeps the loop branch-free
         const void* src = (hoff[j] != NOSRC && s >= 0) ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
         glds16(src, hb + ((j == HPIECES - 1 ? jdup : j) * NWV + wave) * 1024);
     };
-    auto issue_w1 = [&](int i, int kk, char* wb) {   // kk = slice * 9 + tap; < 0: nothing to fetch
+    auto issue_w1 = [&](int i, int kk, char* wb) {   // kk = slice * NTAP + tap; < 0: nothing to fetch
         const void* src = (woffs[i] != NOSRC && kk >= 0) ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
         glds16(src, wb + wpiece(i) * 1024);
     };
     auto issue_h_tap = [&](int tap, int s, char* hb) {      // the halo pieces that go out with tap `tap` of a slice
-        if (NWV == 8) {
+        if (SUB) {
+            if (tap < 3) {
+                issue_h(2 * tap, s, hb);
+                issue_h(2 * tap + 1, s, hb);
+            } else {
+                issue_h(6, s, hb);
+            }
+        } else if (NWV == 8) {
             if (tap < 7) issue_h(tap, s, hb);
         } else if (tap < 5) {
             issue_h(2 * tap, s, hb);
@@ -207,6 +234,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
         return hp * 128 + (DT ? (((2 * lq) ^ swz_of(hp, 1)) << 4) : ((lq ^ (hp & 7)) << 4));
     };
 
+    auto frag_addr_sub = [&](int f, int t) -> int {  // SUB: tap t = (ty, tx) of this item's phase
+        const int hp = hbase[f] + ((hrc[f] >> 16) + (phase >> 1) + (t >> 1) - 1) * PW + ((hrc[f] & 0xffff) + (phase & 1) + (t & 1) - 1);
+        return hp * 128 + ((lq ^ (hp & 7)) << 4);
+    };
+
     f32x4 acc[TN][TM];
     bf16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
     int xan[TM];                                  // CARRY: fragment addresses of the NEXT tap (computed under this tap's MFMAs)
@@ -236,8 +268,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
     setup(work);
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, Hb0);
-    issue_w(s_begin * 9, Wb);
-    issue_w(s_begin * 9 + 1, Wb + WBYTES);        // every item has >= 9 K tiles
+    issue_w(s_begin * NTAP, Wb);
+    issue_w(s_begin * NTAP + 1, Wb + WBYTES);     // every item has >= NTAP K tiles
     bool stores_pending = false;                  // exactly FULL_STORES stores were issued after that DMA
     constexpr int FULL_STORES = (TN / 2 + TN % 2) * TM;
 
@@ -274,7 +306,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                 for (int f = 0; f < TM; ++f) asm volatile("" : "+v"(hbase[f]), "+v"(hrc[f]));
             }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < NTAP; ++tap) {
                 // In-order vmcnt: tile kt's W stage (issued two K tiles ago) and, at tap 0, the slice's halo have
                 // landed once only the DMAs of the PREVIOUS iteration -- its halo piece, if any, and the 3 pieces of
                 // W(kt+1) -- may still be pending; on an item's first tile also the predecessor's epilogue stores,
@@ -282,7 +314,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                 // the W stage of tile kt-1 and the halo of slice s-1, which are refilled below.
                 // (4 waves: 13 halo pieces per wave go out two per tap at taps 0-4 and one at taps 5-7, 5 W pieces every tap:
                 // the previous tap issued 0 + 5 before tap 0, 2 + 5 before taps 1-5, 1 + 5 before taps 6-8.)
-                if (DIAG == 0) {
+                if (SUB) {
+                    // 7 halo pieces go out 2-2-2-1 with the four taps, 3 W pieces with every tap: the previous iteration issued
+                    // 1 + 3 before tap 0 (the halo piece first: only the W pieces may be pending), 2 + 3 before taps 1-3
+                    if (tap == 0) {
+                        if (s == s_begin && stores_pending) wait_vmcnt<3 + FULL_STORES>();
+                        else wait_vmcnt<3>();
+                    } else {
+                        wait_vmcnt<5>();
+                    }
+                } else if (DIAG == 0) {
                 if (NWV == 8) {
                 if (tap == 0) {
                     if (s == s_begin && stores_pending) wait_vmcnt<3 + FULL_STORES>();
@@ -309,7 +350,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                 char* wnext = Wb + (wst == 0 ? 2 : wst - 1) * WBYTES;      // stage of tile kt+2 = stage of tile kt-1
                 int xa[TM];
 #pragma unroll
-                for (int f = 0; f < TM; ++f) xa[f] = CARRY ? xan[f] : frag_addr(f, tap);
+                for (int f = 0; f < TM; ++f) xa[f] = CARRY ? xan[f] : SUB ? frag_addr_sub(f, tap) : frag_addr(f, tap);
                 if (CARRY) {
                     // One wave per SIMD: nothing else fills the matrix pipe while this wave issues DMAs or computes
                     // addresses, so both are placed INSIDE the MFMA streams -- a DMA piece every 5 MFMAs of the carried
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(DIAG & 2)) {
                     issue_h_tap(tap, more ? s + 1 : -1, hnext);
-                    issue_w(s * 9 + tap + 2 < s_end * 9 ? s * 9 + tap + 2 : -1, wnext);
+                    issue_w(s * NTAP + tap + 2 < s_end * NTAP ? s * NTAP + tap + 2 : -1, wnext);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(DIAG & 8)) {
@@ -408,7 +449,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
         // ---- epilogue, phase A: every LOAD the epilogue needs, folded into the accumulators now so that
         // no ordinary load is outstanding once the next item's LDS-DMA is in flight ----------------------
         // (accumulator layout as gemm_kernel: a lane owns 4 consecutive channels of one pixel per 16x16 tile)
-        const int em0 = m0, en0 = n0, esplit = split;
+        const int em0 = m0, en0 = n0, esplit = split, ephase = phase;
+        // row of C that holds tile row m (SUB: low-res pixel (b, y, x) of phase (py, px) -> output pixel (2 y + py, 2 x + px))
+        auto crow = [&](int m) -> long {
+            if (!SUB) return m;
+            const int b = m >> lgHW, ml = m & (HWo - 1);
+            return ((long)b * p.Hout + 2 * (ml >> lgW) + (ephase >> 1)) * p.Wout + 2 * (ml & (Wo - 1)) + (ephase & 1);
+        };
         if (DT && p.splitk == 1) {     // dequantise: per-output-channel weight scale / per-tensor activation scale
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
@@ -426,8 +473,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                     const int n = min(en0 + wn * WTN + a * 16 + lq * 4, p.N - 4);
 #pragma unroll
                     for (int b = 0; b < TM; ++b) {
-                        const int m = min(em0 + wm * WTM + b * 16 + lrow, p.M - 1);
-                        rr[a][b] = *(const u32x2*)(p.R + (long)m * p.ldr + n);
+                        const int m = min(em0 + wm * WTM + b * 16 + lrow, Mrows - 1);
+                        rr[a][b] = *(const u32x2*)(p.R + crow(m) * p.ldr + n);
                     }
                 }
 #pragma unroll
@@ -464,9 +511,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
             char* hb = hsel ? Hb1 : Hb0;
 #pragma unroll
             for (int j = 0; j < HPIECES; ++j) issue_h(j, s_begin, hb);
-            issue_w(s_begin * 9, Wb + wst * WBYTES);
-            issue_w(s_begin * 9 + 1, Wb + (wst == 2 ? 0 : wst + 1) * WBYTES);
-            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= p.M) && (en0 + BN <= p.N);
+            issue_w(s_begin * NTAP, Wb + wst * WBYTES);
+            issue_w(s_begin * NTAP + 1, Wb + (wst == 2 ? 0 : wst + 1) * WBYTES);
+            stores_pending = p.splitk == 1 && wide_ok && (em0 + BM <= Mrows) && (en0 + BN <= p.N);
         }
 
         // ---- epilogue, phase B: stores only ----------------------------------------------------------------
@@ -486,10 +533,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
         } else {
             // GroupNorm statistics of this tile for the consuming GroupNorm (64-row blocks = this wave's rows)
             if (p.stats) {
+                // (SUB: the blocks of a sample are contiguous in the row order (sample, phase, low-res pixel) the consumer
+                // expects of a sub-pixel conv: block = (b * 4 + phase) * HW / 64 + block within the phase)
+                const int r0 = em0 + wm * WTM;
+                const int blk0 = SUB ? ((((r0 >> lgHW) << 2) + ephase) << (lgHW - 6)) + ((r0 & (HWo - 1)) >> 6) : r0 >> 6;
 #pragma unroll
                 for (int hb64 = 0; hb64 < TM / 4; ++hb64)       // one 64-row block per 4 pixel tiles
-                    tile_channel_stats<TN, TM>(acc, p.stats, ((em0 + wm * WTM) >> 6) + hb64, p.N, en0 + wn * WTN, p.N,
-                                               em0 + wm * WTM, p.M, lane, 4 * hb64, 4);
+                    tile_channel_stats<TN, TM>(acc, p.stats, blk0 + hb64, p.N, en0 + wn * WTN, p.N,
+                                               em0 + wm * WTM, Mrows, lane, 4 * hb64, 4);
             }
             // v_permlane16_swap pairs two adjacent 16-channel tiles: 16 contiguous bytes per lane and store
             auto store_narrow = [&](int a) {
@@ -500,7 +551,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                     const int m = em0 + wm * WTM + b * 16 + lrow;
                     const f32x4 v = acc[a][b];
                     u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                    if (m < p.M) *(u32x2*)(p.C + (long)m * p.ldc + n) = o;
+                    if (m < Mrows) *(u32x2*)(p.C + crow(m) * p.ldc + n) = o;
                 }
             };
 #pragma unroll
@@ -515,7 +566,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
                         const auto s1 = __builtin_amdgcn_permlane16_swap(pack2bf(vx[2], vx[3]), pack2bf(vy[2], vy[3]), false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         const int col = nb + (lq & 1) * 16 + (lq >> 1) * 8;
-                        if (m < p.M) *(u32x4*)(p.C + (long)m * p.ldc + col) = o;
+                        if (m < Mrows) *(u32x4*)(p.C + crow(m) * p.ldc + col) = o;
                     }
                 } else {
                     store_narrow(a);
@@ -552,6 +603,20 @@ bool sd_conv_halo_applicable(const GemmArgs& a) {
     return true;
 }
 
+// The sub-pixel upsampler (GemmArgs::subpix: four 2x2 convs on the low-res input) on the halo kernel's 4-tap mode: the tile
+// grid is the LOW-RES image; only where (pixel tiles x 4 phases x channel tiles) fills the 256 CUs -- the 8x8 -> 16x16
+// upsampler (128 items at UNet batch 16) stays on the implicit-GEMM kernel's 64-row tiles.  SD_SUBPIX_HALO=0: never.
+bool sd_conv_halo_subpix_applicable(const GemmArgs& a) {
+    const char* env = getenv("SD_SUBPIX_HALO");         // per call: the tests compare the two kernels in one process
+    const bool off = env && atoi(env) == 0;
+    if (off || !a.subpix || a.dt != 0 || a.R != nullptr || (a.splitk > 1 && a.slab) || (a.Hin * a.Win) % 64 != 0) return false;
+    GemmArgs g = a;
+    g.up = 0; g.stride = 1; g.M = a.M / 4;
+    if (!sd_conv_halo_applicable(g)) return false;
+    if ((long)a.N * 4 * a.ldw * 2 >= (1l << 32)) return false;            // 32-bit W offsets over the four phases
+    return (long)((g.M + BM - 1) / BM) * 4 * ((a.N + BN - 1) / BN) >= 256;
+}
+
 // Split-K over channel slices: one 8-wave workgroup per CU, so aim at >= 256 work items.
 int sd_conv_halo_splitk(int M, int N, int Cin, int dt) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -575,10 +640,26 @@ int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int u
 
 int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
-    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_m = ((a.subpix ? a.M / 4 : a.M) + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     if (a.ldw == 0) a.ldw = a.K;
     if (a.slab == nullptr || a.splitk < 1) a.splitk = 1;
+    if (a.subpix) {
+        SD_REQUIRE(a.dt == 0 && a.splitk == 1 && a.R == nullptr && a.up == 0 && a.K == 4 * a.Cin && a.w_batch_stride > 0 &&
+                       a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.M % (4 * a.Hin * a.Win) == 0 && a0.tune == 0,
+                   "conv3x3 halo, sub-pixel upsampler: bf16, no split-K, no residual, K = 4 Cin");
+        static bool sub_attr_set = false;
+        if (!sub_attr_set) {
+            SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 0, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+            sub_attr_set = true;
+        }
+        int g = a.tiles_m * a.tiles_n * 4;
+        if (g > 256) g = 256;
+        a.tune = 0;
+        hipLaunchKernelGGL((conv_halo_kernel<0, 0, 8, 1>), dim3(g), dim3(512), SMEM, stream, a);
+        SD_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int slices = a.Cin / (a.dt ? 128 : 64);
     SD_REQUIRE(a.splitk <= slices, "conv3x3 halo: splitk %d exceeds the %d channel slices", a.splitk, slices);
     static bool attr_set = false;

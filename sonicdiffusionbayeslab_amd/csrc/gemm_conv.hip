@@ -866,6 +866,7 @@ int sd_launch_conv3x3(const GemmArgs& a, hipStream_t stream) {
                        a.up == 0 && (a.Hin * a.Win) % 64 == 0 && a.M % (4 * a.Hin * a.Win) == 0 && a.R == nullptr &&
                        a.zero_page != nullptr && a.w_batch_stride > 0 && !(a.splitk > 1 && a.slab),
                    "conv3x3 sub-pixel upsample: bf16, K = 4 Cin, low-res pixels per sample %% 64 == 0, no residual, no split-K");
+        if (sd_conv_halo_subpix_applicable(a)) return sd_launch_conv3x3_halo(a, stream);     // the halo kernel's 4-tap mode
         // a tile must not straddle two phases: 64-row tiles for 8x8 inputs (no GroupNorm block statistics on that tile)
         if ((a.Hin * a.Win) % 128 != 0) {
             SD_REQUIRE(!a.stats, "conv3x3 sub-pixel upsample: block statistics need low-res pixels per sample %% 128 == 0");

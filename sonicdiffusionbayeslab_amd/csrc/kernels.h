@@ -77,6 +77,7 @@ void sd_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);   // slab -
 // conv_halo.hip: LDS-resident-halo kernel for stride-1 convs on whole-row tiles
 bool sd_conv_halo_applicable(const GemmArgs& a);
 int sd_conv3x3_splitk(int M, int N, int Cin, int Hin, int Win, int stride, int up, int dt = 0);
+bool sd_conv_halo_subpix_applicable(const GemmArgs& a);      // the sub-pixel upsampler on the halo kernel's 4-tap mode
 int sd_launch_conv3x3_halo(const GemmArgs& a, hipStream_t stream);
 
 // GroupNorm over NHWC (optionally a two-tensor channel concat) -> bf16 [B, HW, C1+C2]

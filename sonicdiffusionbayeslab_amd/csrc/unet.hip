@@ -2204,6 +2204,34 @@ extern "C" int sd_op_conv3x3_upsample_subpixel(void* stream, const void* X, cons
     return sd_launch_conv3x3(a, (hipStream_t)stream);
 }
 
+// ... -> GroupNorm(+SiLU) as the plan runs the pair (the up-blocks' Upsample2D feeds the next resnet's norm1): the conv's
+// epilogue delivers the block statistics in the row order (sample, phase, low-res pixel).  Y = conv output [B, 2 Hin, 2 Win,
+// Cout], Yn = normalised output.  Low-res pixels per sample must be a multiple of 128.
+extern "C" int sd_op_conv3x3_upsample_subpixel_groupnorm(void* stream, const void* X, const void* W4, const float* bias, void* Y,
+                                                         int B, int Hin, int Win, int Cin, int Cout, const float* gamma,
+                                                         const float* beta, void* Yn, int groups, float eps, int silu) {
+    if (ensure_zero_page()) return -2;
+    const int HW = 4 * Hin * Win;
+    SD_REQUIRE((Hin * Win) % 128 == 0 && !sd_groupnorm_uses_small(B, HW, Cout, 0, groups),
+               "sd_op_conv3x3_upsample_subpixel_groupnorm: %dx%d -> x2, %d channels: no producer statistics at this size", Hin, Win, Cout);
+    const size_t stats_bytes = (size_t)B * (HW / 64) * Cout * 2 * 4;
+    char* scratch = (char*)op_scratch(stats_bytes + sd_groupnorm_scratch_bytes(B, HW, groups));
+    SD_REQUIRE(scratch, "sd_op_conv3x3_upsample_subpixel_groupnorm: cannot allocate scratch");
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W4; a.bias = bias; a.C = (bf16_t*)Y; a.ldc = Cout;
+    a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = 1; a.up = 0; a.Hout = 2 * Hin; a.Wout = 2 * Win;
+    a.M = 4 * B * Hin * Win; a.N = Cout; a.K = 4 * Cin; a.K1 = a.K; a.zero_page = g_zero_page; a.splitk = 1;
+    a.subpix = 1; a.w_batch_stride = (long)Cout * 4 * Cin;
+    a.stats = (float*)scratch;
+    if (int rc = sd_launch_conv3x3(a, (hipStream_t)stream)) return rc;
+    GroupNormArgs g;
+    g.x1 = (const bf16_t*)Y; g.C1 = Cout; g.gamma = gamma; g.beta = beta; g.y = (bf16_t*)Yn; g.B = B; g.HW = HW;
+    g.groups = groups; g.eps = eps; g.silu = silu; g.nsplit = sd_groupnorm_nsplit(B, HW);
+    g.partial = (float*)(scratch + stats_bytes);
+    g.stats1 = (const float*)scratch;
+    return sd_launch_groupnorm(g, (hipStream_t)stream);
+}
+
 extern "C" int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2, const float* gamma,
                                const float* beta, void* y, int B, int HW, int groups, float eps, int silu) {
     GroupNormArgs a;

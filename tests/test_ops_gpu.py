@@ -170,15 +170,9 @@ def test_conv3x3_halo_four_wave_layout_is_bit_identical(sdlib, B, H, Cin, Cout):
         assert sdlib.sd_op_conv3x3_ablate(stream(), P(xd), P(wd), P(outs[1]), B, H, H, Cin, Cout, mode) != 0
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100), (5, 8, 128, 320)])
-def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
-    """Upsample2D = nearest 2x + 3x3 conv, computed as four 2x2 convs on the low-res input (one per output phase) with
-    summed taps: the same linear map with 4/9 of the multiply-adds; against interpolate + conv2d."""
-    g = torch.Generator().manual_seed(H + Cin + Cout)
-    x = r16(torch.randn(B, Cin, H, H, generator=g))
-    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
-    b = torch.randn(Cout, generator=g)
-    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+def _subpixel_weights(w):
+    """[Cout, Cin, 3, 3] -> [4 phases][Cout][Cin/64][4 taps][64]: the 3x3 taps that read the same low-res pixel, summed."""
+    Cout, Cin = w.shape[:2]
     rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}                       # phase -> 3x3 taps behind 2x2 tap 0 / 1
     w4 = torch.zeros(4, Cout, Cin, 2, 2)
     for py in (0, 1):
@@ -186,12 +180,66 @@ def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
             for dy in (0, 1):
                 for dx in (0, 1):
                     w4[py * 2 + px, :, :, dy, dx] = w[:, :, rows[py][dy]][:, :, :, rows[px][dx]].sum((2, 3))
-    w4p = w4.permute(0, 1, 3, 4, 2).reshape(4, Cout, 4, Cin // 64, 64).permute(0, 1, 3, 2, 4).contiguous()
+    return w4.permute(0, 1, 3, 4, 2).reshape(4, Cout, 4, Cin // 64, 64).permute(0, 1, 3, 2, 4).contiguous()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100), (5, 8, 128, 320),
+                                          (16, 16, 128, 1280),     # >= 256 work items: the halo kernel's 4-tap mode
+                                          (4, 32, 192, 640),       # ... four 256-pixel tiles per image
+                                          (32, 16, 64, 200)])      # ... Cout tail in the second channel tile
+def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
+    """Upsample2D = nearest 2x + 3x3 conv, computed as four 2x2 convs on the low-res input (one per output phase) with
+    summed taps: the same linear map with 4/9 of the multiply-adds; against interpolate + conv2d.  Large grids run on the
+    halo kernel's 4-tap mode (csrc/conv_halo.hip, SUB): same K order and accumulation chains as the implicit-GEMM kernel,
+    so the two agree bit for bit (SD_SUBPIX_HALO=0 selects the latter)."""
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    w4p = _subpixel_weights(w)
     xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
-    out = torch.full((B, 2 * H, 2 * H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
-    _lib.check(sdlib.sd_op_conv3x3_upsample_subpixel(stream(), P(xd), P(w4p, torch.bfloat16), P(b), P(out), B, H, H, Cin, Cout))
-    torch.cuda.synchronize()
+
+    def run():
+        out = torch.full((B, 2 * H, 2 * H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _lib.check(sdlib.sd_op_conv3x3_upsample_subpixel(stream(), P(xd), P(w4p, torch.bfloat16), P(b), P(out), B, H, H, Cin, Cout))
+        torch.cuda.synchronize()
+        return out
+    out = run()
     assert rel_l2(out.permute(0, 3, 1, 2), ref) < TOL
+    os.environ["SD_SUBPIX_HALO"] = "0"
+    try:
+        other = run()
+    finally:
+        del os.environ["SD_SUBPIX_HALO"]
+    assert torch.equal(out.view(torch.int16), other.view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(16, 16, 128, 640),      # halo kernel's 4-tap mode, one tile per image
+                                          (4, 32, 64, 640),        # ... four tiles per image
+                                          (2, 16, 128, 320)])      # implicit-GEMM kernel
+def test_conv3x3_upsample_subpixel_groupnorm_producer_statistics(sdlib, B, H, Cin, Cout):
+    """Upsample2D -> the next resnet's GroupNorm with the statistics from the conv epilogue: 64-row blocks in the row order
+    (sample, phase, low-res pixel), whichever kernel ran the conv."""
+    g = torch.Generator().manual_seed(H + Cin + Cout + 1)
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    conv = r16(F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1))
+    ref = F.silu(F.group_norm(conv, 32, gamma, beta, 1e-5))
+    xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    y = torch.full((B, 2 * H, 2 * H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    yn = torch.full_like(y, float("nan"))
+    _lib.check(sdlib.sd_op_conv3x3_upsample_subpixel_groupnorm(stream(), P(xd), P(_subpixel_weights(w), torch.bfloat16), P(b), P(y),
+                                                               B, H, H, Cin, Cout, P(gamma), P(beta), P(yn), 32, 1e-5, 1))
+    torch.cuda.synchronize()
+    assert rel_l2(y.permute(0, 3, 1, 2), conv) < TOL
+    assert rel_l2(yn.permute(0, 3, 1, 2), ref) < TOL
+    own = torch.full_like(y, float("nan"))
+    _lib.check(sdlib.sd_op_groupnorm(stream(), P(y), Cout, None, 0, P(gamma), P(beta), P(own), B, 4 * H * H, 32, 1e-5, 1))
+    torch.cuda.synchronize()
+    assert rel_l2(yn, own) < 2e-3
 
 
 @pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [
