@@ -24,7 +24,7 @@ stall)   # where the waves' cycles go: parked (WAIT_ANY), issue-stalled (WAIT_IN
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/pmc_traffic/$c
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_traffic/$c -- python $R/tools/forward_once.py > $O/pmc_traffic_$c.log 2>&1 || fail $O/pmc_traffic_$c.log; done
-  (cd $R && python tools/pmc_traffic.py gpurun_out/pmc_traffic "conv_halo_kernel" gpurun_out/r4_conv_traffic.json) ;;
+  (cd $R && python tools/pmc_traffic.py gpurun_out/pmc_traffic "conv_halo_kernel<0, 0, 8, 0>" gpurun_out/r4_conv_traffic.json) ;;
 attn)    # 64x64 self-attention alone: round-2 kernel vs the round-3 one (SD_ATTN_VARIANT 0 / 7)
   bash $R/tools/r3_attn_pmc.sh 0 7 ;;
 stats)
