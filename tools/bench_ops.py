@@ -92,7 +92,7 @@ def main():
             fl = 2.0 * UB * ho * ho * cout * 9 * cin
             print(f"conv res={res:3d} {cin:5d}->{cout:5d} s{stride} up{up}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
     if "subpix" in args.only:
-        for (res, c) in ((32, 640), (16, 1280)):
+        for (res, c) in ((32, 640), (16, 1280), (8, 1280)):
             x = rnd(UB, res, res, c); w4 = rnd(4, c, c // 64, 4, 64); b = torch.zeros(c, device="cuda")
             out = torch.empty(UB, 2 * res, 2 * res, c, device="cuda", dtype=bf)
             ms = timeit(lambda: _lib.check(lib.sd_op_conv3x3_upsample_subpixel(st, x.data_ptr(), w4.data_ptr(), b.data_ptr(), out.data_ptr(), UB, res, res, c, c)))
