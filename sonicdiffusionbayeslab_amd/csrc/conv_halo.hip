@@ -111,7 +111,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
     const int PIX = RW * Wo;                     // output pixels per piece
     const int HP = (BM / PIX) * PP;              // halo slots in use (<= HSLOTS, checked on the host)
 
-    const char* zero = (const char*)p.zero_page;
     const char* Xb = (const char*)p.X;
     const char* Wg = (const char*)p.W;
 
@@ -184,13 +183,22 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
             woffs[i] = n < p.N ? (unsigned)(((SUB ? (long)phase * p.w_batch_stride : 0l) + (long)n * p.ldw) * ESZ + (c << 4)) : NOSRC;
         }
     };
-    auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch (zero page), keeps the loop branch-free
-        const void* src = (hoff[j] != NOSRC && s >= 0) ? (const void*)(Xb + hoff[j] + s * 128) : (const void*)zero;
-        glds16(src, hb + ((j == HPIECES - 1 ? jdup : j) * NWV + wave) * 1024);
+    // LDS-DMA pieces as BUFFER loads (round 4, as gemm_lean.hip): wave-uniform resource + this lane's 32-bit byte offset
+    // (computed once per item) + a scalar offset per slice / K tile.  A piece costs SALU + one VMEM instruction and NO vector
+    // ALU work -- the 64-bit pointer add and the two selects per piece of the flat form were ~24 of the ~55 VALU instructions
+    // a wave issues per tap beside its 40 MFMAs (each of which holds the vector issue port for 8 of its 16 cycles).  Lanes
+    // without a source (padding, tails: offset NOSRC) are out of range and read zeros; "nothing to fetch" (s / kk < 0) is a
+    // resource of zero bytes.  No zero page.
+    const unsigned xbytes = (unsigned)((long)(Mrows / HWo) * p.Hin * p.Win * p.Cin * ESZ);
+    const unsigned wbytes = (unsigned)((long)p.N * p.ldw * ESZ * (SUB ? 4 : 1));
+    auto issue_h = [&](int j, int s, char* hb) {  // s < 0: nothing to fetch, keeps the loop branch-free
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)Xb, 0, (int)(s >= 0 ? xbytes : 0u), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(hb + ((j == HPIECES - 1 ? jdup : j) * NWV + wave) * 1024), 16, (int)hoff[j],
+                                                 s >= 0 ? s * 128 : 0, 0, 0);
     };
     auto issue_w1 = [&](int i, int kk, char* wb) {   // kk = slice * NTAP + tap; < 0: nothing to fetch
-        const void* src = (woffs[i] != NOSRC && kk >= 0) ? (const void*)(Wg + woffs[i] + (long)kk * 128) : (const void*)zero;
-        glds16(src, wb + wpiece(i) * 1024);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)(kk >= 0 ? wbytes : 0u), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(wb + wpiece(i) * 1024), 16, (int)woffs[i], kk >= 0 ? kk * 128 : 0, 0, 0);
     };
     auto issue_h_tap = [&](int tap, int s, char* hb) {      // the halo pieces that go out with tap `tap` of a slice
         if (SUB) {
