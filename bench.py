@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (text encode + loop + VAE decode) report")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of BASELINE configs[2..4] reported under other_configs (N=1 only)")
+    ap.add_argument("--no-parity-full-length", action="store_true",
+                    help="skip config.parity_full_length (50 batch-1 forwards against the committed oracle fixture): with it a "
+                         "rocprofv3 --stats run of this script averages headline and batch-1 launches together")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
@@ -538,8 +541,10 @@ def main():
         res["roofline"] = {"bound": "mfma",
                            "kernel": ("conv_halo_kernel<fp8> (3x3 resnet convs on v_mfma_f32_16x16x128_f8f6f4, LDS-resident input halo)"
                                       if fp8 else
-                                      "conv_halo_kernel (3x3 conv, LDS-resident input halo; the stride-1 convs of a forward: 44 of its 50 conv launches "
-                                      "-- the 3 stride-2 convs and the 3 sub-pixel upsamplers run on the implicit-GEMM kernel, kernel_breakdown.conv3x3_gemm)"),
+                                      "conv_halo_kernel<0,0,8,0> (3x3 conv, LDS-resident input halo, 9-tap mode; the stride-1 convs of a forward: 44 of its "
+                                      "50 conv launches -- the 16x16->32x32 and 32x32->64x64 sub-pixel upsamplers run on the same kernel's 4-tap mode "
+                                      "(kernel_breakdown.conv3x3_halo_subpix), the 3 stride-2 convs and the 8x8->16x16 upsampler on the implicit-GEMM "
+                                      "kernel (kernel_breakdown.conv3x3_gemm))"),
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": None if fp8 else conv_traffic_bytes()[0],
                            "traffic_source": None if fp8 else (conv_traffic_bytes()[1] or TRAFFIC_SOURCE),
@@ -567,8 +572,10 @@ def main():
         traj = gpu_free_running(model, cfg, args, dev) if args.dtype == "bf16" and args.scheduler == "ddim" else None
         res["cpu_baseline"], parity = cpu_baseline(cfg, sd, args, traj)
         res["config"]["parity"] = parity
-    if rank == 0 and world == 1 and is_headline:
+    if rank == 0 and world == 1 and is_headline and not args.no_parity_full_length:
         res["config"]["parity_full_length"] = full_length_parity(model, cfg, sd, args, dev)
+    # the SD_* switches change kernels, split factors and rounding points: a line's environment is part of its result
+    res["config"]["sd_env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SD_")}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -179,17 +179,26 @@ __device__ __forceinline__ f32x2_t ln_mean_rstd(float s, float q, float inv_k, f
     return f32x2_t{mean, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + eps)};
 }
 // SCALAR fused multiply-adds on purpose (and gemm_conv.hip / gemm_lean.hip are built with -fno-slp-vectorize so that hipcc
-// does not re-pack them).  Written on f32x4 with __builtin_elementwise_fma this became v_pk_fma_f32 with op_sel / neg
-// modifiers broadcasting (mean, rstd) from the register pair a ds_read2_b64 had just delivered, and on MI355X that form
-// produced, about once per 40 launches of the 64x64 q|k|v projection, ONE accumulator register of lanes 48-63 holding c2
-// alone (the product term gone) -- 16 rows x 1 column of the output equal to the bias; found by the run-to-run determinism
-// test at bench shapes (tests/test_ops_gpu.py), 0 events in 3 x 84 launches with the scalar form, 4 in 3 x 84 with the
-// packed one, 0 with the round-3 expression.  Packed fp32 is also the slower choice beside MFMAs (MI355X_MICROARCH.md).
+// does not re-pack them).  Written on f32x4 with __builtin_elementwise_fma the second multiply-add became
+//     v_pk_fma_f32 d[0:1], t[0:1], mr[0:1], c2[0:1] op_sel:[0,1,0]       (both halves x rstd = the HI dword of the (mean, rstd) pair)
+// and MI355X executes that form -- a packed fp32 instruction whose op_sel feeds the LO result lane from the HI dword of a
+// source -- wrongly about once per 10^7 wave-instructions while the other wave of the SIMD is issuing MFMAs: the LO half
+// of lanes 48-63 loses its product (d = c2 exactly).  Round 4 saw it as 16 rows x 1 column of the q|k|v projection equal to
+// the bias, ~1 launch in 35; round 5 decoded > 100 events (always the lo half, always lanes 48-63, always this instruction,
+// any tile / wave, also with nothing of the wave's own memory traffic in flight; 0 of 2800 launches with scalar FMAs) and
+// measured that it is NOT an MFMA -> VALU distance (tools/probes/mfma_hazard.hip: hipcc's padding equals the hardware's
+// need).  tools/probes/pk_fma_coexec.hip is the stand-alone form; asm_lint.py (PK_OPSEL) fails the build on the
+// instruction form anywhere in the library; tools/lnfold_diag.py + SD_DIAG_LN_PACKED rebuild the failing variant.
 __device__ __forceinline__ f32x4 ln_fold(f32x4 acc, f32x4 c1, float mean, float rstd, f32x4 c2) {   // rstd (acc - mean c1) + c2
+#ifdef SD_DIAG_LN_PACKED     // (tools/build_variant.py: the round-4 form that failed; never in the product build)
+    const f32x4 nm = {-mean, -mean, -mean, -mean}, rs = {rstd, rstd, rstd, rstd};
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(c1, nm, acc), rs, c2);
+#else
     f32x4 r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf(__builtin_fmaf(c1[j], -mean, acc[j]), rstd, c2[j]);
     return r;
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -606,7 +606,8 @@ bool sd_conv_halo_applicable(const GemmArgs& a) {
     if (BM % PIX || (H * W) % PIX || (a.up && (RW & 1))) return false;
     if ((W & (W - 1)) || ((H * W) & (H * W - 1))) return false;   // the kernel decodes pixels with shifts
     if ((BM / PIX) * ((RW >> a.up) + 2) * (a.Win + 2) > HSLOTS) return false;
-    if ((long)a.M * a.Cin * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
+    const long ldw = a.ldw ? a.ldw : a.K;                     // (the launchers default ldw to K after this check)
+    if ((long)a.M * a.Cin * 2 >= (1l << 32) || (long)a.N * ldw * 2 >= (1l << 32)) return false;
     if (a.dt == 1 && a.Cin % 128) return false;
     return true;
 }
@@ -621,7 +622,9 @@ bool sd_conv_halo_subpix_applicable(const GemmArgs& a) {
     GemmArgs g = a;
     g.up = 0; g.stride = 1; g.M = a.M / 4;
     if (!sd_conv_halo_applicable(g)) return false;
-    if ((long)a.N * 4 * a.ldw * 2 >= (1l << 32)) return false;            // 32-bit W offsets over the four phases
+    const long ldw = a.ldw ? a.ldw : a.K;
+    if ((long)a.N * 4 * ldw * 2 >= (1l << 32)) return false;              // 32-bit W offsets over the four phases
+    if (a.w_batch_stride != (long)a.N * ldw) return false;                // the kernel's W range is 4 x N x ldw: phases packed back to back
     return (long)((g.M + BM - 1) / BM) * 4 * ((a.N + BN - 1) / BN) >= 256;
 }
 
@@ -656,6 +659,10 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
         SD_REQUIRE(a.dt == 0 && a.splitk == 1 && a.R == nullptr && a.up == 0 && a.K == 4 * a.Cin && a.w_batch_stride > 0 &&
                        a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.M % (4 * a.Hin * a.Win) == 0 && a0.tune == 0,
                    "conv3x3 halo, sub-pixel upsampler: bf16, no split-K, no residual, K = 4 Cin");
+        // the buffer range of W covers N * ldw * 4 elements: a phase stride other than N * ldw would put later phases
+        // out of range, and the range check would then hand the kernel zeros without an error
+        SD_REQUIRE(a.w_batch_stride == (long)a.N * a.ldw, "conv3x3 halo, sub-pixel upsampler: phase stride %ld != N * ldw = %ld",
+                   a.w_batch_stride, (long)a.N * a.ldw);
         static bool sub_attr_set = false;
         if (!sub_attr_set) {
             SD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<0, 0, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));

@@ -428,7 +428,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
         }
         const float invk = 1.0f / (float)p.K;
         *(f32x2_t*)(lnbuf + lane * 8) = ln_mean_rstd(s, q, invk, p.ln_eps);      // row = lane; every lane needs rows b * 16 + lrow
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (see gemm_lean.hip: explicit wait between this write and the reads)
         f32x2_t mr[TM];
 #pragma unroll
         for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + (b * 16 + lrow) * 8);

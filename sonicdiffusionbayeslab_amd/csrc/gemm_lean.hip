@@ -19,6 +19,7 @@
 // gemm_kernel; sd_launch_gemm decides (gemm_conv.hip).  Reference call site: src/models.py:227-235.
 #include "common.h"
 #include "kernels.h"
+#include <mutex>
 
 namespace {
 
@@ -252,12 +253,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
                 q += e[1];
             }
             *(f32x2_t*)(lnbuf + wave * 512 + lane * 8) = ln_mean_rstd(s, q, p.inv_k, p.ln_eps);   // row = lane; lanes need rows 16 b + lrow
-            // The reads below take OTHER lanes' (mean, rstd) from this wave's slots.  An explicit wait between the write and
-            // the reads: without it the first launch on cold caches of the 8-wave GEGLU instantiation (NP = 8, M = 16384)
-            // differed from every later launch in 16 x a few elements, 3 trials of 3; with it never (gpurun_out/r4 logs).
-            // LDS operations of one wave are documented as in-order, so this should not be needed -- it costs one LDS
-            // round trip per item and is kept until the mechanism is understood.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (The reads below take OTHER lanes' (mean, rstd) from this wave's slots; LDS operations of one wave execute in
+            // order, no wait is needed between the write and the reads.  Round 4 kept an explicit s_waitcnt lgkmcnt(0) here
+            // because the first launch of the 8-wave GEGLU instantiation differed in a few dozen elements without it: that
+            // was the packed-FMA erratum of common.h::ln_fold -- the wait only moved the timing; with the scalar fold 0 of
+            // 1400 launches deviate without it, profiles/round5_notes.md.)
             f32x2_t mr[TM];
 #pragma unroll
             for (int b = 0; b < TM; ++b) mr[b] = *(const f32x2_t*)(lnbuf + wave * 512 + (b * 16 + lrow) * 8);
@@ -423,14 +423,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_lean_kernel(con
     }
 }
 
-// zeros for an absent bias vector (the kernel always fetches two vectors of N floats)
+// zeros for an absent bias vector (the kernel always fetches two vectors of N floats).  One vector per device, created under
+// a lock; the blocking copy back orders the memset (legacy stream) before ANY later launch, also one on a non-blocking
+// stream -- the first GEMM of a model can be the fp8 calibration pass, whose scales persist; a failed allocation or
+// memset leaves nothing behind, so the next call tries again instead of handing out an unzeroed buffer.
 static const float* zero_vector() {
-    static float* z = nullptr;
-    if (!z) {
-        if (hipMalloc((void**)&z, 16384 * 4) != hipSuccess) return nullptr;
-        if (hipMemset(z, 0, 16384 * 4) != hipSuccess) return nullptr;
+    static std::mutex mu;
+    static float* z[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!z[dev]) {
+        float* p = nullptr;
+        float probe = 1.f;
+        if (hipMalloc((void**)&p, 16384 * 4) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 16384 * 4) != hipSuccess || hipMemcpy(&probe, p + 16383, 4, hipMemcpyDeviceToHost) != hipSuccess || probe != 0.f) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        z[dev] = p;
     }
-    return z;
+    return z[dev];
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NP, bool GEGLU>

@@ -2066,8 +2066,18 @@ extern "C" int sd_unet_forward_profiled(sd_unet* u, void* stream, const float* l
         const Op& o = pl->ops[i];
         double fl, by;
         op_work(o, &fl, &by);
-        // (20: the convs that run on the implicit-GEMM kernel -- stride 2 and the sub-pixel upsamplers -- apart from the halo kernel's)
-        const int kd = o.kind == OP_XATTN ? 18 : o.kind == OP_REPLICATE ? 19 :
+        // 4: the stride-1 convs on conv_halo_kernel's 9-tap mode (the roofline kernel); 21: the sub-pixel upsamplers that
+        // sd_launch_conv3x3 puts on its 4-tap mode; 20: what runs on the implicit-GEMM kernel -- the stride-2 convs and the
+        // sub-pixel upsamplers the 4-tap mode does not take (8x8 -> 16x16 at the bench batch).  The SAME predicate as the launch.
+        bool halo4 = false;
+        if (o.kind == OP_CONV3 && !o.dt && o.subpix) {
+            GemmArgs a;
+            a.M = o.M; a.N = o.N; a.K = o.K; a.K1 = o.K; a.Hin = o.Hin; a.Win = o.Win; a.Cin = o.Cin; a.Hout = o.Hout; a.Wout = o.Wout;
+            a.stride = o.stride; a.up = 0; a.subpix = 1; a.splitk = o.splitk; a.slab = (float*)(o.aux >= 0 ? (void*)1 : nullptr);
+            a.w_batch_stride = (long)o.N * 4 * o.Cin;
+            halo4 = sd_conv_halo_subpix_applicable(a);
+        }
+        const int kd = o.kind == OP_XATTN ? 18 : o.kind == OP_REPLICATE ? 19 : halo4 ? 21 :
                        (o.kind == OP_CONV3 && !o.dt && (o.subpix || o.stride != 1)) ? 20 :
                        (o.dt ? (o.kind == OP_CONV3 ? 16 : 17) : o.kind);
         kind_ms[kd] += ms; kind_launches[kd] += 1; kind_flops[kd] += fl; kind_bytes[kd] += by;

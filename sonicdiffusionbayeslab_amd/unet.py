@@ -183,7 +183,7 @@ class HipUNet2DConditionModel:
 
     KIND_NAMES = {0: "sinusoid", 1: "gemv", 2: "conv_in", 3: "groupnorm", 4: "conv3x3", 5: "gemm", 6: "layernorm",
                   7: "attention", 8: "conv_out", 16: "conv3x3_fp8", 17: "gemm_fp8", 18: "xattn_fused",
-                  19: "replicate", 20: "conv3x3_gemm"}
+                  19: "replicate", 20: "conv3x3_gemm", 21: "conv3x3_halo_subpix"}
 
     def forward_profiled(self, latents: torch.Tensor, unet_batch: int, timestep: float, cache_mode: int = CACHE_OFF):
         """One forward with a hipEvent pair around every launch (measurement only, synchronises).

@@ -10,6 +10,9 @@ bit-identical to the stored ones before comparing anything):
   ddim50      configs[1]: DDIM 50 steps, CFG 7.5, batch 1, synth_inputs seed 29 -- latents after steps 10/20/30/40/50
   dpmpp20     configs[2]: DPM-Solver++ (order 2, final sigma zero) 20 steps, CFG 7.5, batch 1, seed 31 -- after 10/20
   deepcache50 configs[3]: DeepCache N = 3, branch 0 on DDIM 50 steps, CFG 7.5, batch 1, seed 41 -- after 10/20/30/40/50
+  ddim50_b8   configs[1] at the HEADLINE batch: DDIM 50 steps, CFG 7.5, batch 8 (UNet batch 16: the rep = 2 CFG plan, the
+              128-row tiles, no split-K at the upper levels, the arena of bench.py), seed 43 -- samples 0 and 7 after steps
+              10/20/30/40 and all 8 samples after step 50 (round 5; ~25 min of oracle on its own)
   lcm4        configs[4]: LCM 4 steps, no CFG, batch 2, seed 33, re-noising tensors from seed 8 -- after every step
   lcm4_fp8    the same loop under oracle.fp8.Fp8Emulation with the per-tensor activation scales of an ORACLE-side
               calibration (Fp8AmaxRecorder at t = 999 / 499 / 259 on the loop's own initial latents, margin 2: the
@@ -42,7 +45,8 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loop_golden_64.n
 WEIGHTS_SEED = 1234
 DPM_KW = dict(solver_order=2, algorithm_type="dpmsolver++", final_sigmas_type="zero")
 LCM_NOISE_SEED = 8
-SEEDS = {"ddim50": 29, "dpmpp20": 31, "deepcache50": 41, "lcm4": 33}
+SEEDS = {"ddim50": 29, "dpmpp20": 31, "deepcache50": 41, "lcm4": 33, "ddim50_b8": 43}
+B8_PROBES = (0, 7)
 
 
 def weights_fingerprint(sd) -> str:
@@ -59,7 +63,7 @@ def lcm_noise(cfg, batch):
 
 
 def main():
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 8)))
     cfg = UNetConfig(sample_size=64)
     ocfg = oracle_cfg(cfg)
     sd = make_synthetic_state_dict(cfg, seed=WEIGHTS_SEED)
@@ -108,6 +112,17 @@ def main():
         keep("deepcache50", traj, 10)
         save()
         print(f"deepcache50 done at {time.time() - t0:.0f} s", flush=True)
+
+    if not have("ddim50_b8"):
+        lat, pe, ne = synth_inputs(cfg, 8, seed=SEEDS["ddim50_b8"])
+        out["ddim50_b8/init"] = lat.numpy()
+        _, _, _, traj = sample_loop(sd, ocfg, DDIMOracle(), pe, ne, lat, 50, 7.5)
+        for i, x in enumerate(traj["latents"]):
+            if (i + 1) % 10 == 0:
+                x = x.float()
+                out[f"ddim50_b8/step{i + 1}"] = (x if i + 1 == 50 else x[list(B8_PROBES)]).numpy()
+        save()
+        print(f"ddim50_b8 done at {time.time() - t0:.0f} s", flush=True)
 
     lat, pe, ne = synth_inputs(cfg, 2, seed=SEEDS["lcm4"])
     noise = lcm_noise(cfg, 2)

@@ -641,30 +641,60 @@ def test_model_registry_entries_are_the_pipeline_classes():
         assert models_registry[name] is cls and isinstance(cls, type) and callable(getattr(cls, "from_pretrained"))
 
 
-def test_attention_inline_asm_reads_are_covered_by_their_counted_waits():
-    """csrc/attention.hip (SD_ATTN_VARIANT 7, the 64x64 self-attention) reads its V^T fragments with inline-asm
-    ds_read_b64_tr_b16 and waits for them a group later with literal lgkmcnt counts; build.py checks the compiler's output on
-    every build (tools/check_lds_waits.py) and keeps the checked .s: the same check here, plus two mutations of that .s
-    that the checker must catch (a wait that is one too lax; a copy of a fragment register ahead of its wait)."""
-    import importlib.util
+def _library_asm():
+    """lib/<unit>.s of every translation unit, left behind by the build that produced the objects (build.py, -save-temps).
+    Skips when the build cannot be (re)done here; rebuilds when a source is newer than its assembly."""
     import os
+    import shutil
+    from sonicdiffusionbayeslab_amd import build as B
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    have_hipcc = os.path.exists(hipcc) or shutil.which("hipcc") is not None
+    inputs = [os.path.normpath(os.path.join(B.CSRC, h)) for h in B.HEADERS]
+    stale = [src for src in B.SOURCES if B._newer(os.path.join(B.CSRC, src), B.asm_path(src)) or any(B._newer(h, B.asm_path(src)) for h in inputs)]
+    if stale:
+        if not have_hipcc:
+            pytest.skip(f"no hipcc here and the assembly of {stale} is missing or older than its source")
+        B.build_library(verbose=False)
+    return {src.split(".")[0]: B.asm_path(src) for src in B.SOURCES}
+
+
+def test_library_assembly_passes_the_hazard_lint_and_the_lint_catches_mutations():
+    """sonicdiffusionbayeslab_amd/asm_lint.py on the assembly of the objects in the tree (the build fails on a violation; this
+    re-checks what is there) and, for every rule, a mutation of real assembly that the rule must catch:
+    PK_OPSEL (the v_pk_fma_f32 op_sel form MI355X mis-executes beside MFMAs: round 4's LayerNorm-fold wrong result),
+    STORE_SOFF (16-byte buffer store with an SGPR soffset: round 4, hazard 1), MFMA_DIST (a VALU read of an MFMA result
+    before the hardware's measured minimum), LDS_WAITS (csrc/attention.hip's hand-counted lgkmcnt: a wait one too lax, a
+    copy of a fragment register ahead of its wait)."""
     import re
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("check_lds_waits", os.path.join(root, "tools", "check_lds_waits.py"))
-    chk = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(chk)
-    path = os.path.join(root, "sonicdiffusionbayeslab_amd", "lib", "attention.s")
-    if not os.path.exists(path):
-        from sonicdiffusionbayeslab_amd.build import build_library
-        build_library()
-    text = open(path).read()
-    kernels = list(chk.kernel_bodies(text, "attn_pipe40_kernelILi7"))
+    from sonicdiffusionbayeslab_amd import asm_lint as L
+    paths = _library_asm()
+    for unit, path in paths.items():
+        assert L.lint_file(path, unit, verbose=False) == [], (unit, L.lint_file(path, unit, verbose=False)[:3])
+    # ---- LDS_WAITS on the 64x64 self-attention kernel
+    text = open(paths["attention"]).read()
+    kernels = list(L.kernels(text, "attn_pipe40_kernelILi7"))
     assert len(kernels) == 1
     name, body = kernels[0]
-    errs, n_tr = chk.check_kernel(name, body)
+    errs, n_tr = L.check_lds_waits(name, body)
     assert n_tr >= 32 and errs == [], errs[:3]
     lax = body.replace("s_waitcnt lgkmcnt(6)", "s_waitcnt lgkmcnt(7)", 1)
-    assert lax != body and chk.check_kernel(name, lax)[0]
+    assert lax != body and L.check_lds_waits(name, lax)[0]
     m = re.search(r"ds_read_b64_tr_b16 (v\[(\d+):\d+\]),[^\n]*\n", body)
     early = body[:m.end()] + f"\tv_mov_b32_e32 v255, v{m.group(2)}\n" + body[m.end():]
-    assert chk.check_kernel(name, early)[0]
+    assert L.check_lds_waits(name, early)[0]
+    # ---- PK_OPSEL / STORE_SOFF / MFMA_DIST on the LayerNorm-fold GEMM
+    name, body = next(L.kernels(open(paths["gemm_lean"]).read(), "gemm_lean_kernelILi128ELi160ELi2ELi2ELi4E"))
+    assert L.check_pk_opsel(name, body) == [] and L.check_store_soffset(name, body) == [] and L.check_mfma_distance(name, body) == []
+    m = re.search(r"\tv_fma_f32 (v\d+), (v\d+), (v\d+), (v\d+)\n", body)
+    packed = body[:m.start()] + "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]\n" + body[m.start():]
+    assert len(L.check_pk_opsel(name, packed)) == 1
+    ok_form = body[:m.start()] + "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n" + body[m.start():]
+    assert L.check_pk_opsel(name, ok_form) == []                      # (the hi-lane selection never failed on the hardware)
+    m = re.search(r"buffer_store_dwordx4 (v\[\d+:\d+\]), (v\d+), (s\[\d+:\d+\]), 0 offen", body)
+    soff = body.replace(m.group(0), f"buffer_store_dwordx4 {m.group(1)}, {m.group(2)}, {m.group(3)}, s31 offen", 1)
+    assert len(L.check_store_soffset(name, soff)) == 1
+    mf = list(re.finditer(r"\tv_mfma_f32_16x16x32_bf16 v\[(\d+):\d+\],[^\n]*\n", body))[-1]
+    early_read = body[:mf.end()] + f"\ts_nop 5\n\tv_add_f32_e32 v255, 1.0, v{mf.group(1)}\n" + body[mf.end():]      # 6 wait states < 8
+    assert any("MFMA_DIST" in e for e in L.check_mfma_distance(name, early_read))
+    fine_read = body[:mf.end()] + f"\ts_nop 7\n\tv_add_f32_e32 v255, 1.0, v{mf.group(1)}\n" + body[mf.end():]       # hipcc's own padding
+    assert L.check_mfma_distance(name, fine_read) == []

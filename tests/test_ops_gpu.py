@@ -186,7 +186,9 @@ def _subpixel_weights(w):
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 320), (1, 32, 64, 192), (3, 16, 320, 100), (5, 8, 128, 320),
                                           (16, 16, 128, 1280),     # >= 256 work items: the halo kernel's 4-tap mode
                                           (4, 32, 192, 640),       # ... four 256-pixel tiles per image
-                                          (32, 16, 64, 200)])      # ... Cout tail in the second channel tile
+                                          (32, 16, 64, 200),       # ... Cout tail in the second channel tile
+                                          (48, 8, 128, 1280)])     # 8x8 input with UNet batch >= 32 (batch 16 + CFG): the 4-tap mode's
+                                                                   # multi-image tiles (4 images per 256-pixel tile; 12 x 4 x 8 = 384 items)
 def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
     """Upsample2D = nearest 2x + 3x3 conv, computed as four 2x2 convs on the low-res input (one per output phase) with
     summed taps: the same linear map with 4/9 of the multiply-adds; against interpolate + conv2d.  Large grids run on the
@@ -218,6 +220,7 @@ def test_conv3x3_upsample_as_four_subpixel_convs(sdlib, B, H, Cin, Cout):
 @pytest.mark.parametrize("B,H,Cin,Cout", [(16, 16, 128, 640),      # halo kernel's 4-tap mode, one tile per image
                                           (4, 32, 64, 640),        # ... four tiles per image
                                           (2, 16, 128, 320)])      # implicit-GEMM kernel
+                                                                   # (8x8 inputs carry no producer statistics: 64-pixel phases)
 def test_conv3x3_upsample_subpixel_groupnorm_producer_statistics(sdlib, B, H, Cin, Cout):
     """Upsample2D -> the next resnet's GroupNorm with the statistics from the conv epilogue: 64-row blocks in the row order
     (sample, phase, low-res pixel), whichever kernel ran the conv."""

@@ -1,0 +1,142 @@
+// Stand-alone reproducer for the round-4 LayerNorm-fold wrong result (profiles/round5_notes.md): does v_pk_fma_f32 with an
+// op_sel broadcast (lo half <- HI dword of src1, the form hipcc emits for  acc * {rstd, rstd} + c2  with (mean, rstd) in one
+// register pair) drop its product term in lanes 48-63 when ANOTHER wave of the same SIMD is streaming MFMAs?
+// Waves 0-3 of a 512-thread workgroup run blocks of 32 packed FMAs on per-lane data and compare every half with scalar
+// v_fma_f32 results computed from the same registers; waves 4-7 (their SIMD partners) run one of: nothing, a
+// v_mfma_f32_16x16x32_bf16 stream, an LDS read stream, a scalar-FMA stream.  Forms tested:
+//   0  v_pk_fma_f32 d, a, s, c op_sel:[0,1,0]                          (both halves multiply by s.hi: the failing stage)
+//   1  v_pk_fma_f32 d, a, s, c op_sel_hi:[1,0,1] neg_lo/neg_hi on src1  (both halves multiply by -s.lo: the first stage)
+//   2  v_pk_fma_f32 d, a, b, c                                          (no operand selection)
+//   3  v_pk_mul_f32 d, a, s op_sel:[0,1]
+// Development probe: hipcc --offload-arch=gfx950 -O3 tools/probes/pk_fma_coexec.hip -o /tmp/pk_fma_coexec && /tmp/pk_fma_coexec
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define PK0(d) "v_pk_fma_f32 v[" #d "], %[a], %[s], %[c] op_sel:[0,1,0]\n\t"
+#define PK1(d) "v_pk_fma_f32 v[" #d "], %[a], %[s], %[c] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+#define PK2(d) "v_pk_fma_f32 v[" #d "], %[a], %[s], %[c]\n\t"
+#define PK3(d) "v_pk_mul_f32 v[" #d "], %[a], %[s] op_sel:[0,1]\n\t"
+#define BLOCK16(P) P(100:101) P(102:103) P(104:105) P(106:107) P(108:109) P(110:111) P(112:113) P(114:115) \
+                   P(116:117) P(118:119) P(120:121) P(122:123) P(124:125) P(126:127) P(128:129) P(130:131)
+// compare all 16 results with the first one (they are the same instruction on the same operands): OR of the XORs per half
+#define CMP_PAIR(d0, d1) "v_xor_b32 v140, v100, v" #d0 "\n\tv_or_b32 %[elo], %[elo], v140\n\tv_xor_b32 v141, v101, v" #d1 "\n\tv_or_b32 %[ehi], %[ehi], v141\n\t"
+#define CMP_ALL CMP_PAIR(102, 103) CMP_PAIR(104, 105) CMP_PAIR(106, 107) CMP_PAIR(108, 109) CMP_PAIR(110, 111) CMP_PAIR(112, 113) \
+    CMP_PAIR(114, 115) CMP_PAIR(116, 117) CMP_PAIR(118, 119) CMP_PAIR(120, 121) CMP_PAIR(122, 123) CMP_PAIR(124, 125) CMP_PAIR(126, 127) \
+    CMP_PAIR(128, 129) CMP_PAIR(130, 131)
+#define CLOB "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",   \
+    "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130",      \
+    "v131", "v140", "v141"
+
+template <int FORM>
+__device__ __forceinline__ void block(f32x2 a, f32x2 s, f32x2 c, unsigned& elo, unsigned& ehi, f32x2& first) {
+    // 16 identical packed instructions into 16 register pairs, then: differences against the FIRST pair (OR-ed), and the first
+    // pair itself for the comparison with the scalar reference
+#define RUN(P) asm volatile(BLOCK16(P) "s_nop 3\n\t" CMP_ALL "v_mov_b32 %[f0], v100\n\tv_mov_b32 %[f1], v101\n\t"          \
+                            : [elo] "+v"(elo), [ehi] "+v"(ehi), [f0] "=&v"(first[0]), [f1] "=&v"(first[1])                 \
+                            : [a] "v"(a), [s] "v"(s), [c] "v"(c) : CLOB)
+    if constexpr (FORM == 0) RUN(PK0);
+    else if constexpr (FORM == 1) RUN(PK1);
+    else if constexpr (FORM == 2) RUN(PK2);
+    else RUN(PK3);
+}
+
+template <int FORM>
+__global__ __launch_bounds__(512) void probe(const float* data, const bf16x8* ops, unsigned* res, int iters, int partner) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave >= 4) {
+        if (partner == 1) {                    // bare MFMA stream
+            const bf16x8 a = ops[lane], b = ops[64 + lane];
+            f32x4 acc[4] = {};
+            for (int it = 0; it < iters * 5; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+            if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) res[0] = 1;
+        } else if (partner == 2) {             // LDS read stream
+            f32x4 s = {};
+            for (int it = 0; it < iters * 8; ++it) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s += *(const f32x4*)(smem + ((tid * 16 + i * 8192 + it * 64) & 32767));
+            }
+            if (s[0] + s[1] == 12345.678f) res[0] = 1;
+        } else if (partner == 3) {             // scalar FMA stream
+            float x = data[tid], y = 1.0001f;
+            for (int it = 0; it < iters * 40; ++it) { x = __builtin_fmaf(x, y, 0.5f); y = __builtin_fmaf(y, 0.9999f, x * 1e-9f); }
+            if (x + y == 12345.678f) res[0] = 1;
+        }
+        return;
+    }
+    const int g = (blockIdx.x * 4 + wave) * 64 + lane;
+    f32x2 a = {data[(g * 6 + 0) & 65535], data[(g * 6 + 1) & 65535]};
+    f32x2 s = {data[(g * 6 + 2) & 65535], data[(g * 6 + 3) & 65535]};
+    f32x2 c = {data[(g * 6 + 4) & 65535], data[(g * 6 + 5) & 65535]};
+    unsigned n_self_lo = 0, n_self_hi = 0, n_ref_lo = 0, n_ref_hi = 0, n_c_lo = 0;
+    for (int it = 0; it < iters; ++it) {
+        unsigned elo = 0, ehi = 0;
+        f32x2 first;
+        block<FORM>(a, s, c, elo, ehi, first);
+        float rlo, rhi;
+        if (FORM == 0) { rlo = __builtin_fmaf(a[0], s[1], c[0]); rhi = __builtin_fmaf(a[1], s[1], c[1]); }
+        else if (FORM == 1) { rlo = __builtin_fmaf(a[0], -s[0], c[0]); rhi = __builtin_fmaf(a[1], -s[0], c[1]); }
+        else if (FORM == 2) { rlo = __builtin_fmaf(a[0], s[0], c[0]); rhi = __builtin_fmaf(a[1], s[1], c[1]); }
+        else { rlo = a[0] * s[1]; rhi = a[1] * s[1]; }
+        n_self_lo += elo != 0; n_self_hi += ehi != 0;
+        n_ref_lo += __builtin_bit_cast(unsigned, first[0]) != __builtin_bit_cast(unsigned, rlo);
+        n_ref_hi += __builtin_bit_cast(unsigned, first[1]) != __builtin_bit_cast(unsigned, rhi);
+        // the operands drift a little so that a stuck result cannot hide
+        a[0] = __builtin_fmaf(a[0], 1.0000001f, 1e-7f); c[1] = __builtin_fmaf(c[1], 0.9999999f, 1e-7f);
+        asm volatile("" : "+v"(a), "+v"(s), "+v"(c));
+    }
+    unsigned* o = res + 16 + g * 4;
+    o[0] = n_self_lo; o[1] = n_self_hi; o[2] = n_ref_lo; o[3] = n_ref_hi;
+    (void)n_c_lo;
+}
+
+static const char* form_name[] = {"v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel_hi:[1,0,1] neg", "v_pk_fma_f32 (plain)", "v_pk_mul_f32 op_sel:[0,1]"};
+static const char* partner_name[] = {"partner idle", "partner MFMA stream", "partner LDS reads", "partner scalar FMAs"};
+
+template <int FORM>
+void run(const float* data, const bf16x8* ops, unsigned* res, int blocks, int iters) {
+    for (int partner = 0; partner < 4; ++partner) {
+        hipMemset(res, 0, (16 + blocks * 256 * 4) * 4);
+        hipLaunchKernelGGL(probe<FORM>, dim3(blocks), dim3(512), 32768, 0, data, ops, res, iters, partner);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
+        std::vector<unsigned> h(16 + blocks * 256 * 4);
+        hipMemcpy(h.data(), res, h.size() * 4, hipMemcpyDeviceToHost);
+        unsigned long tot[4] = {0, 0, 0, 0}, grp[4][4] = {};
+        for (int g = 0; g < blocks * 256; ++g)
+            for (int k = 0; k < 4; ++k) { tot[k] += h[16 + g * 4 + k]; grp[k][(g & 63) >> 4] += h[16 + g * 4 + k]; }
+        printf("  %-22s: blocks of 16 x %-36s %d per lane: a later result != the first one: lo %lu hi %lu | first result != scalar fma: lo %lu hi %lu"
+               " | lo-half events by lane group 0-15 %lu, 16-31 %lu, 32-47 %lu, 48-63 %lu\n",
+               partner_name[partner], form_name[FORM], iters, tot[0], tot[1], tot[2], tot[3], grp[0][0] + grp[2][0], grp[0][1] + grp[2][1],
+               grp[0][2] + grp[2][2], grp[0][3] + grp[2][3]);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 100000;
+    std::vector<float> hd(65536);
+    srand(7);
+    for (auto& x : hd) x = ((rand() % 20001) - 10000) / 4000.0f;
+    std::vector<unsigned short> ho(128 * 8);
+    for (auto& x : ho) x = (unsigned short)(((rand() & 1) << 15) | ((124 + rand() % 6) << 7) | (rand() & 127));
+    float* data; bf16x8* ops; unsigned* res;
+    const int blocks = 256;
+    hipMalloc(&data, hd.size() * 4); hipMalloc(&ops, ho.size() * 2); hipMalloc(&res, (16 + blocks * 256 * 4) * 4);
+    hipMemcpy(data, hd.data(), hd.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ops, ho.data(), ho.size() * 2, hipMemcpyHostToDevice);
+    run<0>(data, ops, res, blocks, iters);
+    run<1>(data, ops, res, blocks, iters);
+    run<2>(data, ops, res, blocks, iters);
+    run<3>(data, ops, res, blocks, iters);
+    return 0;
+}
