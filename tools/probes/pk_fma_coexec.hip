@@ -67,6 +67,15 @@ __global__ __launch_bounds__(512) void probe(const float* data, const bf16x8* op
                 for (int i = 0; i < 4; ++i) s += *(const f32x4*)(smem + ((tid * 16 + i * 8192 + it * 64) & 32767));
             }
             if (s[0] + s[1] == 12345.678f) res[0] = 1;
+        } else if (partner == 4) {             // a GEMM-like stream: LDS fragment reads + MFMAs
+            f32x4 acc[4] = {};
+            for (int it = 0; it < iters * 4; ++it) {
+                const bf16x8 a = *(const bf16x8*)(smem + ((tid * 16 + it * 1024) & 32767));
+                const bf16x8 b = *(const bf16x8*)(smem + ((tid * 16 + it * 1024 + 8192) & 32767));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+            }
+            if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) res[0] = 1;
         } else if (partner == 3) {             // scalar FMA stream
             float x = data[tid], y = 1.0001f;
             for (int it = 0; it < iters * 40; ++it) { x = __builtin_fmaf(x, y, 0.5f); y = __builtin_fmaf(y, 0.9999f, x * 1e-9f); }
@@ -101,11 +110,11 @@ __global__ __launch_bounds__(512) void probe(const float* data, const bf16x8* op
 }
 
 static const char* form_name[] = {"v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel_hi:[1,0,1] neg", "v_pk_fma_f32 (plain)", "v_pk_mul_f32 op_sel:[0,1]"};
-static const char* partner_name[] = {"partner idle", "partner MFMA stream", "partner LDS reads", "partner scalar FMAs"};
+static const char* partner_name[] = {"partner idle", "partner MFMA stream", "partner LDS reads", "partner scalar FMAs", "partner LDS reads + MFMAs"};
 
 template <int FORM>
 void run(const float* data, const bf16x8* ops, unsigned* res, int blocks, int iters) {
-    for (int partner = 0; partner < 4; ++partner) {
+    for (int partner = 0; partner < 5; ++partner) {
         hipMemset(res, 0, (16 + blocks * 256 * 4) * 4);
         hipLaunchKernelGGL(probe<FORM>, dim3(blocks), dim3(512), 32768, 0, data, ops, res, iters, partner);
         if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
