@@ -1,65 +1,17 @@
 # Round-5 profile passes (each its own rocprofv3 run: --pmc only with --kernel-trace; the program itself after `--`).
-# usage: tools/run_profiles_r5.sh [stats] [fwd] [stall] [traffic] [xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn] [attn]      outputs: gpurun_out/r5_*; copy to profiles/round5_*
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp; exattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-port TMPDIR=/tmp
+# usage: tools/run_profiles_r5.sh [stats] [fwd] [stall] [traffic] [xa] [attn]      outputs: gpurun_out/r5_*; copy to profiles/round5_*
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
-fail() { grep -v "^    @" $1 | tail -5; exattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-it 1; }
+fail() { grep -v "^    @" $1 | tail -5; exit 1; }
 for step in "$@"; do case $step in
 stats)   # HEADLINE workload only: no other_configs, no end-to-end, no CPU baseline, no batch-1 full-length parity loop
   rm -rf $O/r5_stats
   ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-other-configs --no-parity-full-length"
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r5_stats -- python $R/bench.py $ARGS > $O/r5_stats_bench.log 2>&1 || fail $O/r5_stats_bench.log
   F=$(find $O/r5_stats -name "*kernel_stats.csv"); N=$(echo "$F" | wc -l)
-  [ "$N" = "1" ] || { echo "exattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-pected ONE kernel_stats.csv (one profiled process), found $N: $F"; exattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-it 1; }
+  [ "$N" = "1" ] || { echo "expected ONE kernel_stats.csv (one profiled process), found $N: $F"; exit 1; }
   (cd $R && SHA=$(python -c "from bench import kernel_sources_sha16; print(kernel_sources_sha16())") &&
-   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (headline workload only: 2 xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
- 50 forwards at UNet batch 16 + 2 profiled forwards)"; echo "# kernel_sources_sha16=$SHA  source=$(basename $F)"; cat $F; } > $O/r5_bench_kernel_stats.csv)
+   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (headline workload only: 2 x 50 forwards at UNet batch 16 + 2 profiled forwards)"; echo "# kernel_sources_sha16=$SHA  source=$(basename $F)"; cat $F; } > $O/r5_bench_kernel_stats.csv)
   tail -1 $O/r5_stats_bench.log > $O/r5_bench_line_under_rocprof.json; cut -c1-200 $O/r5_bench_line_under_rocprof.json; head -8 $O/r5_bench_kernel_stats.csv | cut -c1-160 ;;
 fwd)
   rm -rf $O/r5_pmc_fwd
@@ -74,99 +26,15 @@ traffic)   # HBM bytes of the dominant kernel AND of the HBM-bound ones (north_s
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/r5_pmc_traffic/$c -- python $R/tools/forward_once.py > $O/r5_pmc_traffic_$c.log 2>&1 || fail $O/r5_pmc_traffic_$c.log; done
   (cd $R && python tools/pmc_traffic_multi.py gpurun_out/r5_pmc_traffic gpurun_out/r5_conv_traffic.json "conv_halo_kernel<0, 0, 8, 0>" "conv_halo_kernel<0, 0, 8, 1>" \
      "gn_apply_kernel" "gn_small_kernel" "gn_finalize_stats_kernel" "layernorm_grouped_kernel" "gemm_lean_kernel<128, 160, 2, 2, 4, false>" "gemm_lean_kernel<256, 256, 4, 2, 2, true>" \
-     "gemm_lean_kernel<128, 160, 2, 2, 0, false>" "attn_pipe40_kernel" "xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
+     "gemm_lean_kernel<128, 160, 2, 2, 0, false>" "attn_pipe40_kernel" "xattn_fused_kernel" "splitk_reduce_kernel" | cut -c1-260) ;;
+xa)      # fused cross-attention: the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048
+         # samples: 2.6 / 10 ms) -- GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS
+         # give-back), and the busy fraction is a quotient over that clock
   for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
     grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
   (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
      launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_fused_kernel" "splitk_reduce_kernel" | cut -c1-260) ;;
-xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn)
-  for n in 64 16; do rm -rf $O/r5_pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_b$n
-    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_b$n -- python $R/tools/xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_stamps.py $n 4096 320 > $O/r5_pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_b$n.log 2>&1 || fail $O/r5_pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_b$n.log; done
-  (cd $R && python tools/pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_json.py gpurun_out/r5_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_pmc.json launch_64_samples=gpurun_out/r5_pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_b64 launch_16_samples_bench=gpurun_out/r5_pmc_xattn)   # the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048 samples: 2.6 / 10 ms):
-         # GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back), and
-         # the busy fraction is a quotient over that clock
-  for n in 16 64 512 2048; do rm -rf $O/r5_pmc_xattn_b$n
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/r5_pmc_xattn_b$n -- python $R/tools/xattn_stamps.py $n 4096 320 > $O/r5_pmc_xattn_b$n.log 2>&1 || fail $O/r5_pmc_xattn_b$n.log
-    grep -E "per launch|8-wave|launch span" $O/r5_pmc_xattn_b$n.log; done
-  (cd $R && python tools/pmc_xattn_json.py gpurun_out/r5_xattn_pmc.json launch_16_samples_bench=gpurun_out/r5_pmc_xattn_b16 launch_64_samples=gpurun_out/r5_pmc_xattn_b64 \
-     launch_512_samples=gpurun_out/r5_pmc_xattn_b512 launch_2048_samples=gpurun_out/r5_pmc_xattn_b2048) ;;
-attn_b16) ;;
 attn)
   bash $R/tools/r3_attn_pmc.sh 7 && cp $O/r3_attn_pmc.json $O/r5_attn_pmc.json ;;
 esac; done
