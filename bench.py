@@ -453,6 +453,15 @@ def other_configs(model, args, dev, sdist, sd):
     prof = m8.unet.forward_profiled(lat8, 32, 501.0)
     prof = m8.unet.forward_profiled(lat8, 32, 501.0)
     c8, g8 = prof["conv3x3_fp8"], prof["gemm_fp8"]
+    # where the fp8 forward's time goes, next to the bf16 model's forward at the SAME batch (32, no CFG): the accounting behind
+    # "what would fp8 have to remove to pay more" 
+    model.unet.set_deepcache(-1)
+    model.unet.set_context(torch.randn((32, model.unet_config.context_len, model.unet_config.cross_attention_dim), device=dev))
+    p16 = model.unet.forward_profiled(lat8, 32, 501.0)
+    p16 = model.unet.forward_profiled(lat8, 32, 501.0)
+    brk = lambda pr: {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in pr.items() if v["launches"]}
+    fwd_breakdown = {"fp8_e4m3": brk(prof), "bf16": brk(p16), "fp8_total_ms": round(sum(v["ms"] for v in prof.values()), 3),
+                     "bf16_total_ms": round(sum(v["ms"] for v in p16.values()), 3), "unet_batch": 32}
     # quality next to the speed: one UNet forward (batch 2, t = 499, same latents / prompt embeddings) of the fp8 model against
     # the bf16 model of this run -- the error of the e4m3 scheme (calibrated per-tensor scales) on these synthetic weights
     gq = torch.Generator().manual_seed(31)
@@ -469,7 +478,7 @@ def other_configs(model, args, dev, sdist, sd):
     out.append({"workload": "configs[4] per-GPU share: LCM 4 steps, no CFG, batch 32, fp8-e4m3 weights + activations in the "
                             "resnet conv / FF / QKV / proj_in contractions", "value": ips, "unit": "images/s",
                 "ms_per_step": ms, "steps": 2, "warmup": 1, "dtype": "fp8_e4m3", "loop_only_s_per_image": loop_secs / (2 * 32),
-                "fp8_forward_vs_bf16": fp8_err,
+                "fp8_forward_vs_bf16": fp8_err, "forward_breakdown_ms": fwd_breakdown,
                 "fp8_activation_scales": {"tensors": len(scales), "calibrated": sum(1 for _, a in scales.values() if a > 0),
                                           "min_scale": min(s for s, _ in scales.values()) if scales else None,
                                           "max_scale": max(s for s, _ in scales.values()) if scales else None,

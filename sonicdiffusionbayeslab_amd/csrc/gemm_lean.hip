@@ -20,6 +20,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -532,6 +533,9 @@ int sd_launch_gemm_lean(const GemmArgs& g, int epi, int rows, hipStream_t stream
         a.hm_tok_shift = sh; a.hm_heads = g.hm_C / 40; a.hm_samples = g.M / g.hm_tok;
     }
     if (epi == 1) {
+        // (round 5: 128 x 128 tiles on 4 waves, two independent workgroups per CU -- so that one's GELU epilogue overlaps the other's
+        // K loop -- measured 8 % SLOWER at every FF shape, bit-identical: 133 -> 144 us at 64x64, 117 -> 128 at 32x32, 117 -> 125 at
+        // 16x16, tools/geglu_tile_ab.py; the doubled LDS-fill bytes per flop cost more than the overlap returns)
         if (!g.ln_rs) return launch_lean<256, 256, 4, 2, 0, true>(a, stream);
         return g.ln_np == 2 ? launch_lean<256, 256, 4, 2, 2, true>(a, stream)      // (2 partials: the fused cross-attention's, one slice)
              : g.ln_np == 4 ? launch_lean<256, 256, 4, 2, 4, true>(a, stream)
