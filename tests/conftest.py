@@ -16,3 +16,10 @@ def pytest_configure(config):
 def sdlib():
     from sonicdiffusionbayeslab_amd import _lib
     return _lib.load()
+
+
+def pytest_report_header(config):
+    """The SD_* switches select kernels, split factors and rounding points: a parity run's environment is part of
+    its result, so it is printed with it (none set = the product defaults)."""
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SD_")}
+    return f"SD_* environment: {env if env else 'none set (product defaults)'}"
