@@ -271,7 +271,10 @@ def test_unet_forward_fp8_matches_emulating_oracle(small_fp8, t):
 
 
 def test_lcm_loop_fp8(small_fp8):
-    """BASELINE configs[4] at reduced size: 4-step LCM sampling, no CFG, pre-drawn noise, fp8 weights."""
+    """BASELINE configs[4] at reduced size: LCM sampling without CFG, pre-drawn noise, fp8 weights, through the pipeline with its
+    own calibration.  Two steps here (the emulating oracle costs ~15 s per step on the GPU box's host; round 4: 114 s of the
+    suite's 600): the FULL 4-step loop at 64x64 runs from the committed fixture in seconds
+    (tests/test_benchshapes_gpu.py::test_full_length_loops_at_64x64_against_the_oracle_fixtures[lcm4_fp8])."""
     from oracle.fp8 import Fp8Emulation
     from oracle.pipeline import sample_loop
     from oracle.schedulers import LCMOracle
@@ -283,17 +286,17 @@ def test_lcm_loop_fp8(small_fp8):
     model.scheduler = schedulers_registry["lcm_scheduler"].from_config(PNDMConfigStub().config)
     lat, pe, _ = synth_inputs(cfg, 2, seed=17)
     g = torch.Generator().manual_seed(8)
-    noise = torch.randn(3, 2, 4, 16, 16, generator=g)
-    out, secs, _ = model(prompt_embeds=pe, latents=lat, num_inference_steps=4, guidance_scale=0.0,
+    noise = torch.randn(1, 2, 4, 16, 16, generator=g)
+    out, secs, _ = model(prompt_embeds=pe, latents=lat, num_inference_steps=2, guidance_scale=0.0,
                          output_type="latent", step_noise=noise.cuda())
     assert "fp8_e4m3" in model.weights_source
     scales = model.unet.fp8_scales(with_amax=True)       # the pipeline calibrated them on its fixed seeded batch before the loop
     assert scales and all(a > 0 for _, a in scales.values()) and "calibrated" in model.weights_source
-    ref_q, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise,
+    ref_q, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 2, 0.0, lcm_noise=noise,
                                  fq=Fp8Emulation(sd, scales={k: v[0] for k, v in scales.items()}))
-    ref, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 4, 0.0, lcm_noise=noise)
+    ref, _, _, _ = sample_loop(sd, oracle_cfg(cfg), LCMOracle(), pe, None, lat, 2, 0.0, lcm_noise=noise)
     e_q, e_f = rel_l2(out.images, ref_q), rel_l2(out.images, ref)
-    print(f"LCM 4 steps fp8: vs emulating oracle {e_q:.3e} cos {cosine(out.images, ref_q):.5f}; vs unquantised oracle "
+    print(f"LCM 2 steps fp8: vs emulating oracle {e_q:.3e} cos {cosine(out.images, ref_q):.5f}; vs unquantised oracle "
           f"{e_f:.3e}; loop {secs * 1e3:.1f} ms")
     assert e_q < LOOP_TOL and cosine(out.images, ref_q) > 0.99
 
