@@ -259,13 +259,13 @@ def end_to_end(model, args, dev):
     return best
 
 
-PROFILE_ROUND = "round4"
+PROFILE_ROUND = "round5"
 TRAFFIC_FILE = f"profiles/{PROFILE_ROUND}_conv_traffic.json"
 PMC_FILE = f"profiles/{PROFILE_ROUND}_pmc_forward.json"
-TRAFFIC_SOURCE = (f"{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_traffic.sh over "
+TRAFFIC_SOURCE = (f"{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/run_profiles_r5.sh traffic over "
                   "tools/forward_once.py at this bench shape; NOT measured in this run; nulled when the kernel sources "
                   "have changed since that profile was taken)")
-PMC_SOURCE = (f"{PMC_FILE} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of tools/run_pmc_forward.sh; "
+PMC_SOURCE = (f"{PMC_FILE} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of tools/run_profiles_r5.sh fwd; "
               "NOT measured in this run; nulled when the kernel sources have changed since)")
 
 
