@@ -216,7 +216,7 @@ def check_lds_waits(name: str, body: str):
 
 
 # kernels whose inline-asm LDS reads are waited for with hand-counted lgkmcnt, per translation unit
-LDS_WAIT_KERNELS = {"attention": ["attn_pipe40_kernel"]}
+LDS_WAIT_KERNELS = {"attention": ["attn_pipe40_kernel", "attn_pipe80_kernel"]}
 
 
 def lint_file(path: str, unit: str | None = None, verbose: bool = True):

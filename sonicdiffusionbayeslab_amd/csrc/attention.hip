@@ -46,6 +46,22 @@ __device__ __forceinline__ float half_pair_max(float x) {
 
 __device__ __forceinline__ int pi_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
+// XCD-aware work order of the pipelined kernels (round 5).  They are launched on a 1-D grid of nq x heads x B workgroups;
+// the hardware deals consecutive workgroups round-robin over the 8 XCDs (MI355X_MICROARCH.md: speed only, never
+// correctness), so with (query block, head, sample) taken straight from a 3-D blockIdx the query blocks of ONE (sample, head)
+// land on ALL eight XCDs and every XCD's L2 streams every head's K / V from beyond it: rocprofv3 counted 680 MB per launch
+// of the 64x64 self-attention = 8 x its 84 MB of K / V (profiles/round5_conv_traffic.json).  Here XCD x takes a CONTIGUOUS
+// run of virtual work items, query block fastest: all query blocks of a (sample, head) share one L2 and its K / V is fetched once.
+__device__ __forceinline__ void xcd_work_item(int nq, int heads, int xcd_order, int& qblk, int& head, int& b) {
+    const int G = gridDim.x, L = blockIdx.x;
+    const int q = G >> 3, r = G & 7, xcd = L & 7, idx = L >> 3;
+    const int v = xcd_order ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : L;       // bijective for every G
+    qblk = v % nq;
+    const int rest = v / nq;
+    head = rest % heads;
+    b = rest / heads;
+}
+
 template <int D>
 struct AttnCfg {
     static constexpr int DK = (D + 15) / 16 * 16;          // QK^T contraction length (zero padded)
@@ -555,8 +571,9 @@ __global__ __launch_bounds__(PipeCfg::NW * 64, 3) void attn_pipe40_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * (NW * 32) + wave * 32 + r;
+    int qblk, head, b;
+    xcd_work_item((a.Nq + NW * 32 - 1) / (NW * 32), a.heads, a.xcd_order, qblk, head, b);
+    const int q = qblk * (NW * 32) + wave * 32 + r;
     const bool qvalid = q < a.Nq;
     const float c = a.q_prescaled ? 1.0f : a.scale * 1.4426950408889634f;
     const char* zero = (const char*)a.consts;
@@ -919,7 +936,8 @@ int launch_attn_pipe40(const AttnArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     constexpr int QB = PipeCfg::NW * 32;
-    dim3 grid((a.Nq + QB - 1) / QB, a.heads, a.B);
+    SD_REQUIRE((long)((a.Nq + QB - 1) / QB) * a.heads * a.B < (1l << 31), "attention: grid too large");
+    dim3 grid(((a.Nq + QB - 1) / QB) * a.heads * a.B);          // 1-D: the kernel derives an XCD-aware (query block, head, sample)
     // SD_ATTN_VARIANT: 0 = the round-2 kernel, bits see the kernel (A/B: 0, 1, 3, 7)
     static const int variant = getenv("SD_ATTN_VARIANT") ? atoi(getenv("SD_ATTN_VARIANT")) & 7 : 7;
     const dim3 blk(PipeCfg::NW * 64);
@@ -927,6 +945,312 @@ int launch_attn_pipe40(const AttnArgs& a, hipStream_t stream) {
     else if (variant == 1) hipLaunchKernelGGL(attn_pipe40_kernel<1>, grid, blk, PipeCfg::SMEM, stream, a);
     else if (variant == 3) hipLaunchKernelGGL(attn_pipe40_kernel<3>, grid, blk, PipeCfg::SMEM, stream, a);
     else hipLaunchKernelGGL(attn_pipe40_kernel<7>, grid, blk, PipeCfg::SMEM, stream, a);
+    SD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// =====================================================================================================
+// Round 5: the same software pipeline for D = 80 (the 32x32 self-attention: N = Nk = 1024).  attn_kernel<80> stages K / V
+// through registers one tile ahead and runs its tile as a serial chain: 0.26 MFMA busy, and its 1024 workgroups of the bench
+// shape need 1.33 rounds of the 768 slots three 53-KiB workgroups per CU give.  Here: 4 waves x 32 queries, K / V tiles by
+// LDS-DMA into a ring of THREE 24-KiB slots (two workgroups per CU = 512 slots: exactly two rounds), tile t+2 in flight
+// while  phase A: exp2 / pack of S(t) || S(t+1) = K(t+1) . Q^T (10 MFMAs)  and  phase B: max over S(t+1) || O^T += V(t)^T . P(t)^T
+// (12 MFMAs) run.  At d = 80 the tile is MFMA-heavy (22 x 32 cycles against ~550 of VALU), so the softmax reference stays on
+// the VALU (one fma per score) but is STALE like the d = 40 kernel's: M moves only when a tile's maximum exceeds it by 2^8
+// (decided on S(t+1) after PV(t) has completed, so everything at the old reference is rescaled exactly once).
+// V^T fragments by inline-asm ds_read_b64_tr_b16 in two register sets with hand-counted lgkmcnt (asm_lint.py LDS_WAITS checks the
+// compiler's code around them): the builtin makes hipcc wait vmcnt(0) -- the tile in flight -- in front of every tile's first read.
+// =====================================================================================================
+struct Pipe80Cfg {
+    static constexpr int D = 80, KQ = 5, DVT = 3, CD = 10, CHK = 11, CHV = 12, RSK = 176, RSV = 192;
+    static constexpr int KBYTES = 64 * RSK, NI = CHK + CHV, NW = 4;
+    static constexpr int NIW = 6;                      // DMA pieces per wave and iteration: 11 K + 12 V + 1 padding piece
+    // K and V tiles have different lifetimes -- iteration t multiplies K(t+1) and V(t) -- so they live in SEPARATE rings of three:
+    // K(t+1) / V(t) in use, K(t+2), K(t+3) / V(t+1), V(t+2) in flight: two iterations for a tile to land (one unified 24-KiB
+    // slot per tile allows one tile in flight in 80 KiB, and the loop then ran at the DMA latency: 73 us against 82 before)
+    static constexpr int VBYTES = 64 * RSV, NSLOT = 3;
+    static constexpr int VOFF = NSLOT * KBYTES, PADOFF = VOFF + NSLOT * VBYTES;      // 33 KiB of K, 36 KiB of V, the padding piece
+    static constexpr int SMEM = PADOFF + 1024 + 256;   // ... + the tr over-read of the last V row of the last slot
+    static_assert(KBYTES == CHK * 1024 && VBYTES == CHV * 1024 && SMEM <= 80 * 1024, "whole DMA pieces; two workgroups per CU");
+};
+
+__global__ __launch_bounds__(Pipe80Cfg::NW * 64, 2) void attn_pipe80_kernel(const AttnArgs a) {
+    using Cfg = Pipe80Cfg;
+    constexpr int D = Cfg::D, KQ = Cfg::KQ, DVT = Cfg::DVT, CD = Cfg::CD, CHK = Cfg::CHK, CHV = Cfg::CHV;
+    constexpr int RSK = Cfg::RSK, RSV = Cfg::RSV, KBYTES = Cfg::KBYTES, VBYTES = Cfg::VBYTES, NI = Cfg::NI, NIW = Cfg::NIW;
+    constexpr int NW = Cfg::NW, VOFF = Cfg::VOFF, PADOFF = Cfg::PADOFF;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, head, b;
+    xcd_work_item((a.Nq + NW * 32 - 1) / (NW * 32), a.heads, a.xcd_order, qblk, head, b);
+    const int q = qblk * (NW * 32) + wave * 32 + r;
+    const bool qvalid = q < a.Nq;
+    const float c = a.q_prescaled ? 1.0f : a.scale * 1.4426950408889634f;
+    const char* zero = (const char*)a.consts;
+    const char* ones = zero + 256;
+
+    bf16x8 qf[KQ];
+    {
+        const bf16_t* qp = a.Q + ((long)b * a.Nq + (qvalid ? q : 0)) * a.ldq + head * D;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            if (qvalid) qf[kk] = *(const bf16x8*)(qp + kk * 16 + h * 8);
+            else qf[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) asm volatile("" : "+v"(qf[kk]));   // retire the loads before the DMA ring starts
+    }
+
+    // branch-free LDS-DMA descriptors (as attn_pipe40_kernel): per piece a source pointer for tile 0 and a byte step per tile
+    const char* d_ptr[NIW];
+    long d_step[NIW];
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int inst = wave + NW * j;
+        d_ptr[j] = zero; d_step[j] = 0;
+        if (inst < CHK) {
+            const int ch = inst * 64 + lane, key = ch / CHK, part = ch - key * CHK;
+            if (part < CD) {
+                d_ptr[j] = (const char*)(a.K + (long)b * a.Nk * a.ldk + head * D + (long)key * a.ldk + part * 8);
+                d_step[j] = 64 * a.ldk * 2;
+            }
+        } else if (inst < NI) {
+            const int ch = (inst - CHK) * 64 + lane, key = ch / CHV, part = ch - key * CHV;
+            if (part < CD) {
+                d_ptr[j] = (const char*)(a.V + (long)b * a.Nk * a.ldv + head * D + (long)key * a.ldv + part * 8);
+                d_step[j] = 64 * a.ldv * 2;
+            } else if (part == CD) {
+                d_ptr[j] = ones;
+            }
+        }
+    }
+    const int ntiles = a.Nk / 64;                 // >= 3, all full (checked by the launcher)
+    // one batch = the K pieces of tile tk into K slot ks and the V pieces of tile tv into V slot vs (+ the padding piece);
+    // tiles past the end fetch the zero page (their slots are dead)
+    auto issue = [&](int tk, int ks, int tv, int vs) {
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int inst = wave + NW * j;                   // wave-uniform
+            const bool isk = inst < CHK;
+            const int t = isk ? tk : tv;
+            const char* src = t < ntiles ? d_ptr[j] + d_step[j] * t : zero;
+            char* dst = isk ? smem + ks * KBYTES + inst * 1024 : inst < NI ? smem + VOFF + vs * VBYTES + (inst - CHK) * 1024 : smem + PADOFF;
+            glds16(src, dst);
+        }
+    };
+
+    f32x16 o[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+
+    const int kfrag_off = pi_swap23(r) * RSK + h * 16;
+    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int vtr_off = VOFF + (8 * h + q4) * RSV + (16 * g16 + 4 * p4) * 2;
+    const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)vtr_off;
+
+    auto qk = [&](const char* tile, f32x16& s0, f32x16& s1) {
+        const char* kp = tile + kfrag_off;
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp), qf[0], f32x16{}, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + 32 * RSK), qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+        for (int kk = 1; kk < KQ; ++kk) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + kk * 32), qf[kk], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + 32 * RSK + kk * 32), qf[kk], s1, 0, 0, 0);
+        }
+    };
+    auto exp_group = [&](const f32x16& c0, const f32x16& c1, int s2, float mc) -> bf16x8 {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s2 < 2 ? c0[8 * s2 + j] : c1[8 * (s2 - 2) + j], c, -mc));
+        u32x4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+        return __builtin_bit_cast(bf16x8, w);
+    };
+
+    // invariant at the start of iteration t: K(0 .. t+2) and V(0 .. t+1) have been requested, in batches of NIW pieces per wave
+    issue(0, 0, 0, 0);
+    issue(1, 1, 0, 0);                            // (no V tile of its own yet: V(0) again, identical bytes into the same slot)
+    issue(2, 2, 1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");   // K(0), V(0) landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16 sa0, sa1, sb0, sb1;                    // S(t) / S(t+1), roles swap every iteration
+    qk(smem, sa0, sa1);
+    float m_run;                                  // the softmax reference M (a score), exact for tile 0, stale afterwards
+    {
+        float tm = fmaxf(sa0[0], sa1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tm = fmaxf(fmaxf(tm, sa0[i]), sa1[i]);
+        m_run = half_pair_max(tm);
+    }
+    constexpr float STALE = 8.f;                  // log2 of the largest probability before M is moved
+
+    // V^T fragments of P group G (keys 16 G .. 16 G + 15 of the tile) for the three 32-row O^T tiles: six transposed reads into
+    // register set S; READY(S, N): they have landed when at most N LDS operations issued after them are outstanding
+#define SD_VREAD80(S, G)                                                                                    \
+    SD_TR_READ(S##0l, vaddr, (G) * 16 * RSV); SD_TR_READ(S##0h, vaddr, (G) * 16 * RSV + 4 * RSV);           \
+    SD_TR_READ(S##1l, vaddr, (G) * 16 * RSV + 64); SD_TR_READ(S##1h, vaddr, (G) * 16 * RSV + 64 + 4 * RSV); \
+    SD_TR_READ(S##2l, vaddr, (G) * 16 * RSV + 128); SD_TR_READ(S##2h, vaddr, (G) * 16 * RSV + 128 + 4 * RSV);
+#define SD_VREADY80(S, N)                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(S##0l), "+v"(S##0h), "+v"(S##1l), "+v"(S##1h), "+v"(S##2l), "+v"(S##2h) : "n"(N)); \
+    v0 = bf16x8{S##0l[0], S##0l[1], S##0l[2], S##0l[3], S##0h[0], S##0h[1], S##0h[2], S##0h[3]};            \
+    v1 = bf16x8{S##1l[0], S##1l[1], S##1l[2], S##1l[3], S##1h[0], S##1h[1], S##1h[2], S##1h[3]};            \
+    v2 = bf16x8{S##2l[0], S##2l[1], S##2l[2], S##2l[3], S##2h[0], S##2h[1], S##2h[2], S##2h[3]};
+#define SD_PV80(G)                                                                                          \
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[G], o[0], 0, 0, 0);                               \
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[G], o[1], 0, 0, 0);                               \
+    o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, pf[G], o[2], 0, 0, 0);
+
+    // One steady-state iteration (t <= ntiles - 2): consumes S(t) in (c0, c1), produces S(t+1) in (n0, n1).
+    auto steady = [&](int t, int slot, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");     // K(t+1), V(t) landed; K(t+2), V(t+1) may be in flight
+        __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is past QK(t) and PV(t-1)
+        asm volatile("" ::: "memory");
+        const int nslot = slot == 2 ? 0 : slot + 1, fslot = slot == 0 ? 2 : slot - 1;
+        issue(t + 3, slot, t + 2, fslot);                     // K(t+3) into the slot of K(t), V(t+2) into the slot of V(t-1)
+        const char* kp = smem + nslot * KBYTES + kfrag_off;
+        const float mc = m_run * c;
+        bf16x8 kf[2 * KQ];
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            kf[kk] = *(const bf16x8*)(kp + kk * 32);
+            kf[KQ + kk] = *(const bf16x8*)(kp + 32 * RSK + kk * 32);
+        }
+        bf16x8 pf[4], v0, v1, v2;
+        const unsigned vaddr = lds_v + (unsigned)(slot * VBYTES);
+        bf16x4 x0l, x0h, x1l, x1h, x2l, x2h, y0l, y0h, y1l, y1h, y2l, y2h;
+        __builtin_amdgcn_sched_barrier(0);
+        // phase A: two QK^T MFMAs of tile t+1 + exp2 / pack of 8 scores of tile t, four times; then the last k-step
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], f32x16{}, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ], qf[0], f32x16{}, 0, 0, 0);
+        pf[0] = exp_group(c0, c1, 0, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 1], qf[1], n1, 0, 0, 0);
+        pf[1] = exp_group(c0, c1, 1, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[2], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 2], qf[2], n1, 0, 0, 0);
+        pf[2] = exp_group(c0, c1, 2, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3], qf[3], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 3], qf[3], n1, 0, 0, 0);
+        pf[3] = exp_group(c0, c1, 3, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(x, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4], qf[4], n0, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[KQ + 4], qf[4], n1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase B: three PV MFMAs per P group + a quarter of the running max over S(t+1)
+        SD_VREAD80(y, 1) SD_VREADY80(x, 6)
+        SD_PV80(0)
+        float tm0 = fmaxf(n0[0], n1[0]);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) tm0 = fmaxf(fmaxf(tm0, n0[i]), n1[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(x, 2) SD_VREADY80(y, 6)
+        SD_PV80(1)
+#pragma unroll
+        for (int i = 4; i < 8; ++i) tm0 = fmaxf(fmaxf(tm0, n0[i]), n1[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(y, 3) SD_VREADY80(x, 6)
+        SD_PV80(2)
+#pragma unroll
+        for (int i = 8; i < 12; ++i) tm0 = fmaxf(fmaxf(tm0, n0[i]), n1[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREADY80(y, 0)
+        SD_PV80(3)
+#pragma unroll
+        for (int i = 12; i < 16; ++i) tm0 = fmaxf(fmaxf(tm0, n0[i]), n1[i]);
+        const float tmx = half_pair_max(tm0);
+        __builtin_amdgcn_sched_barrier(0);
+        // rare: some query's tile maximum is more than 2^STALE above its reference -> every lane moves M up to its maximum so
+        // far; O (and the row sum in it) is rescaled once, S(t+1) is exponentiated against the new reference next iteration
+        if (!__all((tmx - m_run) * c <= STALE)) {
+            const float m_new = fmaxf(m_run, tmx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int tt = 0; tt < DVT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[tt][i] *= alpha;
+            m_run = m_new;
+        }
+    };
+    auto final_tile = [&](int slot, f32x16& c0, f32x16& c1) {
+        // (what is still in flight fetched the zero page into dead slots)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float mc = m_run * c;
+        bf16x8 pf[4], v0, v1, v2;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) pf[s2] = exp_group(c0, c1, s2, mc);
+        const unsigned vaddr = lds_v + (unsigned)(slot * VBYTES);
+        bf16x4 x0l, x0h, x1l, x1h, x2l, x2h;
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(x, 0) SD_VREADY80(x, 0) SD_PV80(0)
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(x, 1) SD_VREADY80(x, 0) SD_PV80(1)
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(x, 2) SD_VREADY80(x, 0) SD_PV80(2)
+        __builtin_amdgcn_sched_barrier(0);
+        SD_VREAD80(x, 3) SD_VREADY80(x, 0) SD_PV80(3)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#undef SD_VREAD80
+#undef SD_VREADY80
+#undef SD_PV80
+    int t = 0, slot = 0;
+    for (; t + 2 < ntiles; t += 2) {
+        steady(t, slot, sa0, sa1, sb0, sb1);
+        slot = slot == 2 ? 0 : slot + 1;
+        steady(t + 1, slot, sb0, sb1, sa0, sa1);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (t + 2 == ntiles) {                        // even tile count: one more steady step, then the last tile
+        steady(t, slot, sa0, sa1, sb0, sb1);
+        slot = slot == 2 ? 0 : slot + 1;
+        final_tile(slot, sb0, sb1);
+    } else {
+        final_tile(slot, sa0, sa1);
+    }
+
+    // row D of O^T holds sum(P) (ones chunk): tile D/32, row D%32 -> register (RR&3) + 4*(RR>>3), h = 0 half
+    constexpr int TT = D / 32, RR = D % 32, REG = (RR & 3) + 4 * (RR >> 3);
+    static_assert((RR & 4) == 0, "ones row must sit in the h = 0 half");
+    const float inv = 1.0f / __shfl(o[TT][REG], r);
+    if (qvalid) {
+        bf16_t* op = a.O + ((long)b * a.Nq + q) * a.ldo + head * D;
+#pragma unroll
+        for (int tt = 0; tt < DVT; ++tt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dv = 32 * tt + 8 * g4 + 4 * h;
+                if (dv < D) {
+                    u32x2 w = {pack2bf(o[tt][4 * g4 + 0] * inv, o[tt][4 * g4 + 1] * inv),
+                               pack2bf(o[tt][4 * g4 + 2] * inv, o[tt][4 * g4 + 3] * inv)};
+                    *(u32x2*)(op + dv) = w;
+                }
+            }
+        }
+    }
+}
+
+int launch_attn_pipe80(const AttnArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_pipe80_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Pipe80Cfg::SMEM));
+        attr_set = true;
+    }
+    constexpr int QB = Pipe80Cfg::NW * 32;
+    SD_REQUIRE((long)((a.Nq + QB - 1) / QB) * a.heads * a.B < (1l << 31), "attention: grid too large");
+    dim3 grid(((a.Nq + QB - 1) / QB) * a.heads * a.B);          // 1-D: XCD-aware work order inside the kernel
+    hipLaunchKernelGGL(attn_pipe80_kernel, grid, dim3(Pipe80Cfg::NW * 64), Pipe80Cfg::SMEM, stream, a);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -967,7 +1291,12 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
+int sd_launch_attention(const AttnArgs& a0, hipStream_t stream) {
+    AttnArgs a = a0;
+    {
+        const char* e = getenv("SD_ATTN_XCD");          // per call: A/B of the work order in one process
+        if (e && atoi(e) == 0) a.xcd_order = 0;
+    }
     SD_REQUIRE(a.Q && a.K && a.V && a.O, "attention: null operand");
     SD_REQUIRE(a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0, "attention: empty problem");
     if (a.kv_head_major) {
@@ -995,6 +1324,10 @@ int sd_launch_attention(const AttnArgs& a, hipStream_t stream) {
             // measured at the 32x32 level (UNet batch 16): register-staged 79 us vs LDS-DMA 87 us self, 21.5 vs 23.6 us
             // cross -- the 8-wave DMA workgroups only pay off at d = 40; SD_ATTN_DMA80 re-selects the DMA kernel
             static const bool dma80 = getenv("SD_ATTN_DMA80") != nullptr;
+            // round 5: the software-pipelined kernel for key counts that are a multiple of 64 (the 32x32 self-attention);
+            // SD_ATTN_NO_PIPE keeps everything on attn_kernel<80>
+            static const bool no_pipe80 = getenv("SD_ATTN_NO_PIPE") != nullptr;
+            if (dma && !no_pipe80 && !a.kv_head_major && a.Nk % 64 == 0 && a.Nk >= 192) return launch_attn_pipe80(a, stream);
             return (dma && dma80) ? launch_attn_dma<80>(a, stream) : launch_attn<80>(a, stream);
         }
         case 160: return launch_attn<160>(a, stream);

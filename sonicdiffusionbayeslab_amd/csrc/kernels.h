@@ -133,6 +133,8 @@ struct AttnArgs {
     // Q already carries scale * log2(e) (the UNet folds it into W_q before the weight's one rounding): the kernels take
     // the QK^T product as the exp2 argument as it is; `scale` is then ignored
     int q_prescaled = 0;
+    // pipelined kernels: XCD-aware work order (all query blocks of a (sample, head) on one XCD); 0 = dispatch order (A/B: SD_ATTN_XCD=0)
+    int xcd_order = 1;
 };
 int sd_launch_attention(const AttnArgs& a, hipStream_t stream);
 

@@ -536,6 +536,9 @@ def test_layernorm(sdlib, rows, C):
     (1, 8, 64, 64, 160, True),
     (2, 8, 16, 77, 160, False),
     (1, 8, 4096, 4096, 40, False),  # the SD-1.5 64x64 self-attention shape
+    (1, 8, 256, 192, 80, False),    # attn_pipe80_kernel (round 5): odd tile count, the minimum of three tiles
+    (2, 8, 1024, 1024, 80, True),   # ... the SD-1.5 32x32 self-attention shape, a spiked key in the last tile
+    (1, 8, 200, 320, 80, True),     # ... ragged query count (the last workgroup's waves past Nq), five tiles
 ])
 def test_attention(sdlib, B, heads, Nq, Nk, D, spike):
     g = torch.Generator().manual_seed(Nq + D)
