@@ -150,11 +150,28 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 1) void conv_halo_kernel(c
     unsigned woffs[WPW];                         // byte offsets into W
     auto setup = [&](int w) {
         int tile_n, tile_m;
-        if (SUB) {           // n fastest, then the four phases of a pixel tile (they share its halo), no split-K
-            tile_n = w % p.tiles_n;
-            const int q = w / p.tiles_n;
-            phase = q & 3;
-            tile_m = q >> 2;
+        if (SUB) {           // no split-K
+            // Item order (round 5): with 256 workgroups the 32 of one XCD take 32 consecutive items per round.  Pixel tile
+            // slowest (the round-3 order: n fastest, then the four phases of a pixel tile) made those 32 items one or two pixel
+            // tiles x EVERY (phase, channel tile): each XCD streamed the whole 4-phase weight tensor through its L2 every
+            // round (counters: 630 MB fetched per launch for 48 MB of operands).  Now 32 consecutive items are a rectangle of
+            // 8 pixel tiles x 4 (phase, channel tile) panels -- 8 halos + 4 weight panels per XCD-round, the minimum of
+            // a * halo + (32 / a) * panel at both UNet shapes -- and an XCD keeps its panels from round to round where the
+            // pixel tiles allow.  Pixel tiles beyond the last full block of 8 keep the old order.
+            const int C = 4 * p.tiles_n, rect = (p.tiles_m >> 3) * (C >> 2) * 32;
+            const bool rects = gridDim.x == 256 && p.tune == 0;        // tune = 1: SD_SUBPIX_ORDER=0, the round-3 order (A/B)
+            int combo;
+            if (rects && w < rect) {
+                const int r = w >> 5, i = w & 31, bc = r % (C >> 2);
+                tile_m = (r / (C >> 2)) * 8 + (i >> 2);
+                combo = bc * 4 + (i & 3);
+            } else {
+                const int w2 = rects ? w - rect : w;
+                tile_m = (rects ? (p.tiles_m & ~7) : 0) + w2 / C;
+                combo = w2 % C;
+            }
+            tile_n = combo % p.tiles_n;
+            phase = combo / p.tiles_n;
             split = 0; s_begin = 0; s_end = S;
         } else {
             split = w / ntiles;
@@ -670,7 +687,8 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
         }
         int g = a.tiles_m * a.tiles_n * 4;
         if (g > 256) g = 256;
-        a.tune = 0;
+        static const bool old_order = getenv("SD_SUBPIX_ORDER") && atoi(getenv("SD_SUBPIX_ORDER")) == 0;
+        a.tune = old_order ? 1 : 0;
         hipLaunchKernelGGL((conv_halo_kernel<0, 0, 8, 1>), dim3(g), dim3(512), SMEM, stream, a);
         SD_CHECK_HIP(hipGetLastError());
         return 0;
