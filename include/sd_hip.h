@@ -225,6 +225,11 @@ int sd_op_groupnorm(void* stream, const void* x1, int C1, const void* x2, int C2
 int sd_op_conv3x3_groupnorm(void* stream, const void* X, const void* W, const float* bias, const float* bias2,
                             const void* R, void* Y, int B, int Hin, int Win, int Cin, int Cout, const float* gamma,
                             const float* beta, void* Yn, int groups, float eps, int silu);
+/* Small images (the single-launch GroupNorm: <= 256 pixels and <= 10240 values per group) take the same entry point: a
+ * split-K conv then leaves its fp32 partial slabs to the GroupNorm kernel, which finishes the reduce (+ bias + bias2 + R, in
+ * splitk_reduce's order of additions), stores Y and normalises it in ONE launch (SD_GN_SLAB=0: conv + reduce, then the
+ * GroupNorm; bit-identical).  sd_op_conv3x3_splitk: the split factor the library picks for a 3x3 conv (1 = none). */
+int sd_op_conv3x3_splitk(int M, int Cout, int Cin, int Hin, int Win, int stride, int upsample);
 int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows, int C,
                     float eps);
 int sd_op_attention(void* stream, const void* Q, long long ldq, const void* K, long long ldk, const void* V,

@@ -89,6 +89,7 @@ _SIGS = {
     "sd_op_conv3x3_upsample_subpixel_groupnorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i]),
     "sd_op_groupnorm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "sd_op_conv3x3_groupnorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i]),
+    "sd_op_conv3x3_splitk": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sd_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f]),
     "sd_op_attention": (_i, [_vp, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f]),
     "sd_op_gemm_qkv_headmajor": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i]),

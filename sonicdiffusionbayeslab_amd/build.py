@@ -42,7 +42,7 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-m
                # (keeps its explicit packed softmax pairs -- plain operands, 2 % of the kernel; the one horizontal add hipcc turned
                # into the op_sel form is written as a scalar add in the source, and the lint holds the unit to that)
                "xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
-               "small.hip": NO_PACKED_FP32, "clip.hip": NO_PACKED_FP32,
+               "small.hip": NO_PACKED_FP32, "clip.hip": NO_PACKED_FP32, "norm.hip": NO_PACKED_FP32,      # (HBM-bound elementwise kernels)
                # the GEMM epilogues: scalar fp32 stays scalar (common.h::ln_fold: SLP re-packs the LayerNorm fold into
                # v_pk_fma_f32 with op_sel -- the failing form above; packed fp32 is also slower beside MFMAs)
                "gemm_conv.hip": ["-fno-slp-vectorize"], "gemm_lean.hip": ["-fno-slp-vectorize"]}

@@ -672,6 +672,7 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     a.tiles_n = (a.N + BN - 1) / BN;
     if (a.ldw == 0) a.ldw = a.K;
     if (a.slab == nullptr || a.splitk < 1) a.splitk = 1;
+    SD_REQUIRE(!a.defer_reduce || a.splitk > 1, "conv3x3 halo: defer_reduce needs split-K (the consumer would read an unwritten slab)");
     if (a.subpix) {
         SD_REQUIRE(a.dt == 0 && a.splitk == 1 && a.R == nullptr && a.up == 0 && a.K == 4 * a.Cin && a.w_batch_stride > 0 &&
                        a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win && a.M % (4 * a.Hin * a.Win) == 0 && a0.tune == 0,
@@ -734,7 +735,7 @@ int sd_launch_conv3x3_halo(const GemmArgs& a0, hipStream_t stream) {
     if (a.dt) hipLaunchKernelGGL(conv_halo_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
     else hipLaunchKernelGGL(conv_halo_kernel<0>, dim3(grid), dim3(512), SMEM, stream, a);
 #endif
-    if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
+    if (a.splitk > 1 && !a.defer_reduce) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -696,6 +696,7 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     a.tiles_n = (a.N + BN - 1) / BN;
     if (a.ldw == 0) a.ldw = a.K;
     if (EPI != EPI_STD || a.slab == nullptr || a.splitk < 1) a.splitk = 1;
+    SD_REQUIRE(!a.defer_reduce || a.splitk > 1, "gemm: defer_reduce needs split-K (the consumer would read an unwritten slab)");
 #ifdef SD_ABLATE
     static const int tune = getenv("SD_GEMM_TUNE") ? atoi(getenv("SD_GEMM_TUNE")) : 0;
     a.tune = tune;
@@ -716,7 +717,7 @@ int launch(const GemmArgs& a0, hipStream_t stream) {
     constexpr int persistent = smem > 80 * 1024 ? kPersistentGrid / 2 : kPersistentGrid;   // workgroups that fit a CU
     if (STAGES == 2 && grid > persistent) grid = persistent;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, stream, a);
-    if (a.splitk > 1) sd_launch_splitk_reduce(a, stream);
+    if (a.splitk > 1 && !a.defer_reduce) sd_launch_splitk_reduce(a, stream);
     SD_CHECK_HIP(hipGetLastError());
     return 0;
 }

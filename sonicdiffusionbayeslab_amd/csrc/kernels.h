@@ -24,6 +24,9 @@ struct GemmArgs {
     int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, stride = 1, up = 0;
     int splitk = 1;                   // > 1: K is split over blocks, fp32 partials go through `slab`
     float* slab = nullptr;            // [splitk, M, N] fp32 scratch (required when splitk > 1)
+    // split-K only: leave the partial sums in `slab` and launch no splitk_reduce_kernel -- the consuming single-launch
+    // GroupNorm finishes them (GroupNormArgs::slab: same sums in the same order, + bias + bias2 + R, and writes C as well)
+    int defer_reduce = 0;
     const void* zero_page = nullptr;  // >= 16 zero bytes in device memory
     // per-sample W (cross-attention folded into two GEMMs): rows [b*rows_per_batch, (b+1)*rows_per_batch) of X use
     // W + b * w_batch_stride; rows_per_batch must be a multiple of the 128-row tile (0 = one W for all rows)
@@ -93,6 +96,14 @@ struct GroupNormArgs {
     // statistics delivered by the producers of x1 / x2 ([B * HW / 64][C1 or C2][2], see GemmArgs::stats): the statistics
     // pass over the tensor is skipped (both must be given when C2 > 0; HW a multiple of 64)
     const float* stats1 = nullptr; const float* stats2 = nullptr;
+    // Single-launch kernel only: x1 has NOT been written yet -- its producer ran split-K with GemmArgs::defer_reduce and left
+    // `splitk` fp32 partial slabs [splitk][B * HW][C1].  The kernel forms x1 = bf16(sum_s slab[s] + sbias + sbias2 + sR) exactly
+    // as splitk_reduce_kernel would (same order of additions), normalises THAT, and stores it to x1w for x1's other readers:
+    // one launch and one pass over the slabs instead of two launches (round 5: 27 such pairs per SD-1.5 forward at UNet batch 16).
+    const float* slab = nullptr; int splitk = 0;
+    const float* sbias = nullptr; const float* sbias2 = nullptr;   // [C1] fp32, optional
+    const bf16_t* sR = nullptr; long sldr = 0;                     // residual rows, optional
+    bf16_t* x1w = nullptr;                                         // [B * HW][C1]
     float* partial = nullptr;   // workspace of sd_groupnorm_scratch_bytes(): [B,nsplit,groups,2] partials + [B,groups,2] stats
     int B = 0, HW = 0, groups = 32, nsplit = 0;
     float eps = 1e-5f;
@@ -100,6 +111,7 @@ struct GroupNormArgs {
 };
 int sd_groupnorm_nsplit(int B, int HW);
 bool sd_groupnorm_uses_small(int B, int HW, int C1, int C2, int groups);
+bool sd_groupnorm_slab_ok(int B, int HW, int C1, int C2, int groups);     // ... and may finish a deferred split-K reduce
 size_t sd_groupnorm_scratch_bytes(int B, int HW, int groups);
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream);
 

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -223,7 +224,35 @@ __global__ void gn_apply_kernel(const GroupNormArgs a) {
 // data; here the group's HW x cpg values (<= 10 KB) are read twice by the same workgroup (the second time from
 // L1/L2), with a block reduction in between (measured 18 -> 8 us at 8x8, 20 -> 16 us at 16x16 x 1280; wider 16x16 tensors stay on the split path).  Accesses are 8 bytes (4 channels): cpg is a multiple of 4 at these
 // levels (20 / 40 / 60 / 80) but not of 8.
+// MAXU: units of 4 channels per thread (3 / 5 / 10: ceil(HW * cpg / 4 / 256) rounded up; 10 = 10 240 values per group).
+// The per-unit arithmetic lives in three helpers shared with gn_slab_kernel below, which reproduces this kernel's statistics
+// and outputs bit for bit.
+__device__ __forceinline__ float2 gn_unit_sums(const u32x2 v) {         // (sum, sum of squares) of a unit's four bf16 values
+    const float f0 = bflo(v[0]), f1 = bfhi(v[0]), f2 = bflo(v[1]), f3 = bfhi(v[1]);
+    return make_float2((f0 + f1) + (f2 + f3), (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3));
+}
+__device__ __forceinline__ void gn_mean_rstd(float ts, float tq, float cnt, float eps, float& mean, float& rstd) {
+    mean = ts / cnt;
+    rstd = rsqrtf(fmaxf(tq / cnt - mean * mean, 0.f) + eps);
+}
 template <bool SILU, bool FP8>
+__device__ __forceinline__ void gn_unit_store(const GroupNormArgs& a, const u32x2 v, float mean, float rstd, long pix, int c, int C) {
+    const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+    float f[4] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        f[jj] = (f[jj] - mean) * rstd * gm[jj] + bt[jj];
+        if (SILU) f[jj] = silu_f(f[jj]);
+    }
+    if (FP8) {
+        *(unsigned*)((char*)a.y + pix * a.Cpad + c) = pack4fp8(f[0] * a.oscale, f[1] * a.oscale, f[2] * a.oscale, f[3] * a.oscale);
+    } else {
+        u32x2 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
+        *(u32x2*)(a.y + pix * C + c) = o;
+    }
+}
+
+template <bool SILU, bool FP8, int MAXU>
 __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     __shared__ float2 red[4];
     const int C = a.C1 + a.C2, cpg = C / a.groups, upp = cpg >> 2;      // 4-channel units per pixel
@@ -235,8 +264,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
         return c < a.C1 ? a.x1 + (base + p) * a.C1 + c : a.x2 + (base + p) * a.C2 + (c - a.C1);
     };
     // unit i = tid + 256 j  <->  (pixel p, unit k): stepped incrementally, no division in the loops.  The group's values
-    // (<= 10 units of 4 channels per thread) are loaded ONCE, all loads in flight together, and stay in registers.
-    constexpr int MAXU = 10;                         // 10 240 values / 4 per unit / 256 threads
+    // (<= MAXU units of 4 channels per thread) are loaded ONCE, all loads in flight together, and stay in registers.
     const int p0 = tid / upp, k0 = tid - p0 * upp, dp = 256 / upp, dk = 256 - dp * upp;
     u32x2 vals[MAXU];
     int pj[MAXU], kj[MAXU];
@@ -244,10 +272,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
         int p = p0, k = k0;
 #pragma unroll
         for (int j = 0; j < MAXU; ++j) {
-            pj[j] = p; kj[j] = k;
             const bool live = tid + 256 * j < total;
-            const int pc = live ? p : 0, kc = live ? k : 0;              // unconditional load from a valid address
-            vals[j] = *(const u32x2*)src(pc, grp * cpg + kc * 4);
+            pj[j] = live ? p : 0; kj[j] = live ? k : 0;                  // dead units: unconditional loads from a valid address
+            vals[j] = *(const u32x2*)src(pj[j], grp * cpg + kj[j] * 4);
             p += dp; k += dk;
             if (k >= upp) { k -= upp; ++p; }
         }
@@ -256,9 +283,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
 #pragma unroll
     for (int j = 0; j < MAXU; ++j) {
         const bool live = tid + 256 * j < total;
-        const float f0 = bflo(vals[j][0]), f1 = bfhi(vals[j][0]), f2 = bflo(vals[j][1]), f3 = bfhi(vals[j][1]);
-        s += live ? (f0 + f1) + (f2 + f3) : 0.f;
-        q += live ? (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3) : 0.f;
+        const float2 u = gn_unit_sums(vals[j]);
+        s += live ? u.x : 0.f;
+        q += live ? u.y : 0.f;
     }
     s = wave_sum(s);
     q = wave_sum(q);
@@ -266,34 +293,125 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs a) {
     __syncthreads();
     const float ts = (red[0].x + red[1].x) + (red[2].x + red[3].x);
     const float tq = (red[0].y + red[1].y) + (red[2].y + red[3].y);
-    const float cnt = (float)a.HW * (float)cpg;
-    const float mean = ts / cnt;
-    const float rstd = rsqrtf(fmaxf(tq / cnt - mean * mean, 0.f) + a.eps);
+    float mean, rstd;
+    gn_mean_rstd(ts, tq, (float)a.HW * (float)cpg, a.eps, mean, rstd);
 #pragma unroll
     for (int j = 0; j < MAXU; ++j) {
         if (tid + 256 * j >= total) break;
-        const int p = pj[j], c = grp * cpg + kj[j] * 4;
-        const u32x2 v = vals[j];
-        const f32x4 gm = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
-        float f[4] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1])};
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            f[jj] = (f[jj] - mean) * rstd * gm[jj] + bt[jj];
-            if (SILU) f[jj] = silu_f(f[jj]);
-        }
-        if (FP8) {
-            *(unsigned*)((char*)a.y + (base + p) * a.Cpad + c) =
-                pack4fp8(f[0] * a.oscale, f[1] * a.oscale, f[2] * a.oscale, f[3] * a.oscale);
-        } else {
-            u32x2 o = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
-            *(u32x2*)(a.y + (base + p) * C + c) = o;
-        }
+        gn_unit_store<SILU, FP8>(a, vals[j], mean, rstd, base + pj[j], grp * cpg + kj[j] * 4, C);
     }
     if (FP8 && grp == a.groups - 1)       // K-tail padding of every pixel row
         for (int i = tid; i < a.HW * ((a.Cpad - C) >> 4); i += 256) {
             const int pc = (a.Cpad - C) >> 4, p = i / pc, k = i - p * pc;
             *(u32x4*)((char*)a.y + (base + p) * a.Cpad + C + k * 16) = u32x4{0u, 0u, 0u, 0u};
         }
+}
+
+// The same GroupNorm when its first source has NOT been written yet: the producer ran split-K and deferred the reduce
+// (GroupNormArgs::slab).  A unit's four channels are  bf16(slab[0] + slab[1] + ... + bias + bias2 + R)  in splitk_reduce_kernel's
+// order of additions, stored to x1w on the way; the second source of a channel concat stays bf16.  The slabs are 16x the bytes
+// of the bf16 tensor, so the layout follows THEM: a workgroup owns G = max(1, 80 / cpg) whole groups of one sample -- 80 (60)
+// consecutive channels = 320 (240) contiguous bytes of every slab row -- as 32 pixel rows x ncol unit columns of threads; a
+// thread keeps ONE column (its gamma / beta / group are fixed) and MAXI pixels, with MAXI x UNR sixteen-byte loads in flight
+// per trip.  (One 256-thread workgroup per group, as gn_small_kernel, read 160-byte pieces of the slab rows: slower than the
+// two launches it replaced.)  Statistics: every unit's (sum, sum of squares) goes through the LDS and is added up by "virtual
+// threads" in gn_small_kernel's exact order (unit i of a group -> thread i % 256, ascending i; wave butterfly; four waves),
+// so the two paths agree bit for bit.
+template <bool SILU, int MAXI, int UNR>
+__global__ __launch_bounds__(640) void gn_slab_kernel(const GroupNormArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = a.C1 + a.C2, cpg = C / a.groups, upp = cpg >> 2;
+    const int G = cpg >= 80 ? 1 : 80 / cpg, ncol = G * upp;              // groups / unit columns of this workgroup
+    const int b = blockIdx.y, grp0 = blockIdx.x * G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = a.HW * upp;                                        // units of one group
+    float2* su = (float2*)smem;                                          // [G][total]
+    float2* red = su + G * total;                                        // [G][4]
+    const long base = (long)b * a.HW;
+    const int row = tid / ncol, col = tid - row * ncol;
+    const bool active = row < 32;
+    const int gl = col / upp, kk = col - gl * upp;                       // this thread's group (local) and unit inside it
+    const int c = grp0 * cpg + col * 4;
+    const bool from_slab = c < a.C1;
+    u32x2 vals[MAXI];
+    if (active) {
+        if (from_slab) {
+            const long MN = (long)a.B * a.HW * a.C1;
+            long off[MAXI];
+            f32x4 acc[MAXI];
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) {
+                const int p = row + 32 * it;
+                off[it] = (base + (p < a.HW ? p : 0)) * a.C1 + c;        // dead pixels: unconditional loads from a valid address
+                acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int s0 = 0; s0 < a.splitk; s0 += UNR) {                 // (splitk % UNR == 0: checked by the launcher)
+                f32x4 t[MAXI][UNR];
+#pragma unroll
+                for (int it = 0; it < MAXI; ++it)
+#pragma unroll
+                    for (int uu = 0; uu < UNR; ++uu) t[it][uu] = *(const f32x4*)(a.slab + (s0 + uu) * MN + off[it]);
+#pragma unroll
+                for (int it = 0; it < MAXI; ++it)
+#pragma unroll
+                    for (int uu = 0; uu < UNR; ++uu) acc[it] = (s0 + uu == 0) ? t[it][uu] : acc[it] + t[it][uu];
+            }
+            f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+            const bool hb = a.sbias != nullptr, hb2 = a.sbias2 != nullptr;
+            const f32x4 b1 = hb ? *(const f32x4*)(a.sbias + c) : bsum, b2 = hb2 ? *(const f32x4*)(a.sbias2 + c) : bsum;
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) {
+                const int p = row + 32 * it;
+                f32x4 v = acc[it];
+                if (hb) v += b1;
+                if (hb2) v += b2;
+                if (a.sR) {
+                    const u32x2 r = *(const u32x2*)(a.sR + (base + (p < a.HW ? p : 0)) * a.sldr + c);
+                    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+                }
+                vals[it] = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                if (p < a.HW) *(u32x2*)(a.x1w + off[it]) = vals[it];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) {
+                const int p = row + 32 * it;
+                vals[it] = *(const u32x2*)(a.x2 + (base + (p < a.HW ? p : 0)) * a.C2 + (c - a.C1));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int p = row + 32 * it;
+            if (p < a.HW) su[gl * total + p * upp + kk] = gn_unit_sums(vals[it]);
+        }
+    }
+    __syncthreads();
+    // gn_small_kernel's reduction, replayed: four waves per group, virtual thread v = 64 (wave & 3) + lane adds units v, v + 256, ...
+    for (int g0 = 0; g0 < G; g0 += 2) {
+        const int g = g0 + (wave >> 2);
+        if (wave < 8 && g < G) {
+            const int v = (wave & 3) * 64 + lane;
+            float s = 0.f, q = 0.f;
+            for (int i = v; i < total; i += 256) {
+                const float2 u = su[g * total + i];
+                s += u.x;
+                q += u.y;
+            }
+            s = wave_sum(s);
+            q = wave_sum(q);
+            if (lane == 0) red[g * 4 + (wave & 3)] = make_float2(s, q);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float2 r0 = red[gl * 4], r1 = red[gl * 4 + 1], r2 = red[gl * 4 + 2], r3 = red[gl * 4 + 3];
+    float mean, rstd;
+    gn_mean_rstd((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (float)a.HW * (float)cpg, a.eps, mean, rstd);
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int p = row + 32 * it;
+        if (p < a.HW) gn_unit_store<SILU, false>(a, vals[it], mean, rstd, base + p, c, C);
+    }
 }
 
 // one wave per token row; up to 3 chunks of 8 channels per lane (C <= 1536)
@@ -528,6 +646,14 @@ bool sd_groupnorm_uses_small(int B, int HW, int C1, int C2, int groups) {
     return !no_small && HW <= 256 && (long)HW * (C / groups) <= 10240 && (C / groups) % 4 == 0 && C1 % 4 == 0 && B <= 65535;
 }
 
+// the shapes gn_slab_kernel takes (a GroupNorm that finishes its producer's deferred split-K reduce): the single-launch
+// kernel's shapes with whole groups per 80- (60-)channel workgroup and the per-unit sums of a workgroup in <= 64 KiB of LDS
+bool sd_groupnorm_slab_ok(int B, int HW, int C1, int C2, int groups) {
+    if (!sd_groupnorm_uses_small(B, HW, C1, C2, groups)) return false;
+    const int cpg = (C1 + C2) / groups, G = cpg >= 80 ? 1 : 80 / cpg;
+    return cpg >= 20 && cpg <= 80 && groups % G == 0 && C2 % 4 == 0 && (long)B * HW * C1 < (1L << 29);
+}
+
 int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     const int C = a.C1 + a.C2;
     SD_REQUIRE(a.x1 && a.y && a.gamma && a.beta && a.partial, "groupnorm: null operand");
@@ -540,14 +666,49 @@ int sd_launch_groupnorm(const GroupNormArgs& a, hipStream_t stream) {
     SD_REQUIRE(a.nsplit >= 1 && a.nsplit <= a.HW && a.B > 0 && a.HW > 0, "groupnorm: bad split %d for HW=%d", a.nsplit, a.HW);
     const GnGeom g = gn_geom(C, a.groups);
     SD_REQUIRE(g.threads <= 1024, "groupnorm: C=%d too wide", C);
-    if (sd_groupnorm_uses_small(a.B, a.HW, a.C1, a.C2, a.groups)) {
-        if (a.out_fp8) {
-            if (a.silu) hipLaunchKernelGGL((gn_small_kernel<true, true>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((gn_small_kernel<false, true>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
+    if (a.slab) {
+        const int cpg = C / a.groups, G = cpg >= 80 ? 1 : 80 / cpg, ncol = G * (cpg / 4);
+        SD_REQUIRE(a.splitk > 1 && a.splitk <= 64 && a.x1w && !a.out_fp8 && (!a.sR || a.sldr >= a.C1) && (a.C2 == 0 || a.x2),
+                   "groupnorm with a deferred split-K reduce: splitk=%d, bf16 output, x1w and a residual stride >= C1", a.splitk);
+        SD_REQUIRE(sd_groupnorm_slab_ok(a.B, a.HW, a.C1, a.C2, a.groups), "groupnorm with a deferred split-K reduce: HW=%d C=%d+%d "
+                   "is not a shape gn_slab_kernel takes", a.HW, a.C1, a.C2);
+        const dim3 grid(a.groups / G, a.B), blk((32 * ncol + 63) / 64 * 64);
+        const size_t smem = ((size_t)G * a.HW * (cpg / 4) + 4 * G) * sizeof(float2);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, blk, smem, stream, a); };
+        auto pick = [&](auto mi, auto un) {
+            constexpr int MI = decltype(mi)::value, UN = decltype(un)::value;
+            if (a.silu) go(gn_slab_kernel<true, MI, UN>); else go(gn_slab_kernel<false, MI, UN>);
+        };
+        using std::integral_constant;
+        const int iters = (a.HW + 31) / 32, k = a.splitk;
+        if (iters <= 2) {
+            if (k % 8 == 0) pick(integral_constant<int, 2>{}, integral_constant<int, 8>{});
+            else if (k % 4 == 0) pick(integral_constant<int, 2>{}, integral_constant<int, 4>{});
+            else if (k % 2 == 0) pick(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+            else pick(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        } else if (iters <= 4) {
+            if (k % 4 == 0) pick(integral_constant<int, 4>{}, integral_constant<int, 4>{});
+            else if (k % 2 == 0) pick(integral_constant<int, 4>{}, integral_constant<int, 2>{});
+            else pick(integral_constant<int, 4>{}, integral_constant<int, 1>{});
         } else {
-            if (a.silu) hipLaunchKernelGGL((gn_small_kernel<true, false>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((gn_small_kernel<false, false>), dim3(a.groups, a.B), dim3(256), 0, stream, a);
+            if (k % 2 == 0) pick(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+            else pick(integral_constant<int, 8>{}, integral_constant<int, 1>{});
         }
+        SD_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (sd_groupnorm_uses_small(a.B, a.HW, a.C1, a.C2, a.groups)) {
+        const int units = (a.HW * (C / a.groups / 4) + 255) / 256;       // 4-channel units per thread
+        const dim3 grid(a.groups, a.B);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, a); };
+        auto pick = [&](auto mu) {
+            constexpr int MU = decltype(mu)::value;
+            if (a.out_fp8) { if (a.silu) go(gn_small_kernel<true, true, MU>); else go(gn_small_kernel<false, true, MU>); }
+            else { if (a.silu) go(gn_small_kernel<true, false, MU>); else go(gn_small_kernel<false, false, MU>); }
+        };
+        if (units <= 3) pick(std::integral_constant<int, 3>{});
+        else if (units <= 5) pick(std::integral_constant<int, 5>{});
+        else pick(std::integral_constant<int, 10>{});
         SD_CHECK_HIP(hipGetLastError());
         return 0;
     }

@@ -102,6 +102,12 @@ struct Op {
     int heads = 0, D = 0, Nq = 0, Nk = 0;
     long ldq = 0, ldk = 0, ldv = 0, ldo = 0, qoff = 0, koff = 0, voff = 0;
     int silu_in = 0, splitk = 1;
+    // split-K producer + single-launch GroupNorm as ONE reduce (fuse_deferred_reduce): the producer (CONV3 / GEMM) sets `defer`
+    // and launches no splitk_reduce_kernel; the GroupNorm reads the producer's slabs (slab_t, slab_k of them) with its bias /
+    // time-embedding row / residual and writes the producer's output tensor on the way (GroupNormArgs::slab)
+    int defer = 0, slab_t = -1, slab_k = 0, slab_r = -1, slab_b2t = -1;
+    size_t slab_b = NOFF;
+    long slab_b2idx = 0;
     // generalised GEMM operands (VAE attention): W operand taken from an activation tensor, X taken
     // from the weight blob, element offsets into tensors and explicit row strides
     int wt = -1;
@@ -1382,10 +1388,51 @@ bool wrap_skipped(const Wrap& w, int branch) {
     return w.type == 0 ? w.layer_i >= cache_layer_id : w.layer_i > cache_layer_id;
 }
 
-void op_tensors(const Op& o, int ins[9], int& nin) {
+void op_tensors(const Op& o, int ins[12], int& nin) {
     nin = 0;
-    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt, o.s1, o.s2, o.lnrs})
+    for (int t : {o.x1, o.x2, o.r, o.b2t, o.wt, o.s1, o.s2, o.lnrs, o.slab_t, o.slab_r, o.slab_b2t})
         if (t >= 0) ins[nin++] = t;
+}
+
+// A split-K conv / GEMM whose output is first read by a single-launch GroupNorm (the 8x8 and 16x16 levels: every resnet conv,
+// the downsamplers, proj_out) hands its partial slabs to that GroupNorm instead of launching splitk_reduce_kernel: the
+// reduce was a 42 MB pass at the launch floor (8-11 us) followed by a 6-10 us GroupNorm over 2.6 MB (27 pairs per forward at
+// UNet batch 16).  Bit-identical to the two launches (same sums in the same order; SD_GN_SLAB=0: off).  Conditions: bf16,
+// plain [M][N] output, no reader of the output between the two ops, both on the same side of the DeepCache boundary.
+void fuse_deferred_reduce(sd_unet* u, Plan& pl) {
+    if (getenv("SD_GN_SLAB") && atoi(getenv("SD_GN_SLAB")) == 0) return;       // (read when a plan is built: tests build both)
+    const int nops = (int)pl.ops.size();
+    auto skipped = [&](const Op& o) {
+        if (pl.branch < 0) return false;
+        for (int k = 0; k < o.nwrap; ++k)
+            if (wrap_skipped(o.wraps[k], pl.branch)) return true;
+        return false;
+    };
+    std::vector<int> producer(pl.tensors.size(), -1);
+    for (int i = 0; i < nops; ++i)
+        if (pl.ops[i].out >= 0) producer[pl.ops[i].out] = i;
+    for (int g = 0; g < nops; ++g) {
+        Op& G = pl.ops[g];
+        if (G.kind != OP_GN || G.out_fp8 || G.x1 < 0 || !sd_groupnorm_slab_ok(G.B, G.HW, G.C1, G.C2, u->cfg.norm_num_groups)) continue;
+        const int p = producer[G.x1];
+        if (p < 0 || p >= g) continue;
+        Op& P = pl.ops[p];
+        if (P.kind != OP_CONV3 && !(P.kind == OP_GEMM && P.epi == 0)) continue;
+        if (P.splitk <= 1 || P.splitk > 64 || P.aux < 0 || P.dt || P.out_fp8 || P.defer || P.subpix) continue;
+        if (P.kind == OP_GEMM && (P.coff || P.ldc_o || P.hm || P.rs >= 0 || P.lnrs >= 0)) continue;
+        if ((long)G.B * G.HW != P.M || G.C1 != P.N || skipped(P) != skipped(G)) continue;
+        bool first_reader = true;
+        for (int i = p + 1; i < g && first_reader; ++i) {
+            int ins[12], nin;
+            op_tensors(pl.ops[i], ins, nin);
+            for (int k = 0; k < nin; ++k)
+                if (ins[k] == P.out) first_reader = false;
+        }
+        if (!first_reader) continue;
+        P.defer = 1;
+        G.slab_t = P.aux; G.slab_k = P.splitk; G.slab_b = P.b; G.slab_r = P.r;
+        G.slab_b2t = P.kind == OP_CONV3 ? P.b2t : -1; G.slab_b2idx = P.b2idx;
+    }
 }
 
 void assign_memory(sd_unet* u, Plan& pl) {
@@ -1404,7 +1451,7 @@ void assign_memory(sd_unet* u, Plan& pl) {
         }
         for (int i = 0; i < nops; ++i) {
             if (pl.skipped[i]) continue;
-            int ins[9], nin;
+            int ins[12], nin;
             op_tensors(pl.ops[i], ins, nin);
             for (int k = 0; k < nin; ++k) {
                 const int p = producer[ins[k]];
@@ -1417,7 +1464,7 @@ void assign_memory(sd_unet* u, Plan& pl) {
     // lifetimes over the full plan
     for (int i = 0; i < nops; ++i) {
         const Op& o = pl.ops[i];
-        int ins[9], nin;
+        int ins[12], nin;
         op_tensors(o, ins, nin);
         for (int k = 0; k < nin; ++k) pl.tensors[ins[k]].last = std::max(pl.tensors[ins[k]].last, i);
         for (int t : {o.out, o.aux, o.stats, o.rs})
@@ -1478,6 +1525,7 @@ int get_plan(sd_unet* u, int UB, int branch, Plan** out, int rep = 1) {
         Builder b{u, pl, UB, {}};
         b.build();
         SD_REQUIRE(b.error.empty(), "unet: cannot build the plan for batch %d (cache branch %d): %s", UB, branch, b.error.c_str());
+        fuse_deferred_reduce(u, pl);
         assign_memory(u, pl);
         it = u->plans.emplace(key, std::move(pl)).first;
     }
@@ -1512,6 +1560,12 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.B = o.B; a.HW = o.HW; a.groups = u->cfg.norm_num_groups; a.nsplit = o.nsplit; a.eps = o.eps; a.silu = o.silu;
             a.out_fp8 = o.out_fp8; a.Cpad = o.Cpad; a.oscale = o.os;
             a.stats1 = (const float*)T(o.s1); a.stats2 = (const float*)T(o.s2);
+            if (o.slab_t >= 0) {
+                a.slab = (const float*)T(o.slab_t); a.splitk = o.slab_k; a.x1w = (bf16_t*)T(o.x1);
+                a.sbias = o.slab_b != NOFF ? (const float*)(wb + o.slab_b) : nullptr;
+                a.sbias2 = o.slab_b2t >= 0 ? (const float*)T(o.slab_b2t) + o.slab_b2idx : nullptr;
+                a.sR = (const bf16_t*)T(o.slab_r); a.sldr = o.C1;
+            }
             return sd_launch_groupnorm(a, stream);
         }
         case OP_CONV3: {
@@ -1521,7 +1575,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out); a.ldc = o.N;
             a.M = o.M; a.N = o.N; a.K = o.K; a.K1 = o.K;
             a.Hin = o.Hin; a.Win = o.Win; a.Cin = o.Cin; a.Hout = o.Hout; a.Wout = o.Wout; a.stride = o.stride; a.up = o.up;
-            a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
+            a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux); a.defer_reduce = o.defer;
             if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
             a.stats = (float*)T(o.stats);
             if (o.subpix) { a.subpix = 1; a.up = 0; a.w_batch_stride = (long)o.N * 4 * o.Cin; }
@@ -1536,6 +1590,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.R = (const bf16_t*)T(o.r); a.ldr = o.N; a.C = (bf16_t*)T(o.out) + o.coff;
             a.ldc = o.ldc_o ? o.ldc_o : (o.epi == 1 ? o.N / 2 : o.N);
             a.M = o.M; a.N = o.N; a.K = o.K; a.zero_page = g_zero_page; a.splitk = o.splitk; a.slab = (float*)T(o.aux);
+            a.defer_reduce = o.defer;
             a.w_batch_stride = o.wbs; a.rows_per_batch = o.rpb; a.sm_valid = o.sm_valid;
             if (o.dt) { a.dt = 1; a.wscale = (const float*)(wb + o.wsc); a.xscale_inv = 1.0f / o.xs; }
             if (o.out_fp8) { a.out_fp8 = 1; a.oscale = o.os; a.ldc = o.Cpad; }
@@ -2101,8 +2156,9 @@ extern "C" long long sd_unet_forward_op_times(sd_unet* u, void* stream, const fl
         const Op& o = pl->ops[i];
         double fl, by;
         op_work(o, &fl, &by);
-        const int w = snprintf(text + n, (size_t)(cap - n), "%d %d %d %d %d %.5f %.3f %.3f\n", i, (int)o.kind, o.M, o.N, o.K, ms,
-                               fl * 1e-9, by * 1e-6);
+        // (a GroupNorm that finishes its producer's deferred split-K reduce reports the split factor in the K column)
+        const int w = snprintf(text + n, (size_t)(cap - n), "%d %d %d %d %d %.5f %.3f %.3f\n", i, (int)o.kind, o.M, o.N,
+                               o.kind == OP_GN ? o.slab_k : o.K, ms, fl * 1e-9, by * 1e-6);
         if (w < 0 || n + w >= cap) break;
         n += w;
     }
@@ -2260,8 +2316,31 @@ extern "C" int sd_op_conv3x3_groupnorm(void* stream, const void* X, const void* 
                                        const float* gamma, const float* beta, void* Yn, int groups, float eps, int silu) {
     if (ensure_zero_page()) return -2;
     const int HW = Hin * Win;
-    SD_REQUIRE(HW % 64 == 0 && !sd_groupnorm_uses_small(B, HW, Cout, 0, groups),
-               "sd_op_conv3x3_groupnorm: %dx%d x %d channels runs the single-launch GroupNorm (no producer statistics)", Hin, Win, Cout);
+    if (sd_groupnorm_uses_small(B, HW, Cout, 0, groups)) {
+        // small images: the single-launch GroupNorm (no producer statistics); a split-K conv leaves its partial slabs to it
+        // (GemmArgs::defer_reduce, fuse_deferred_reduce above) instead of launching splitk_reduce_kernel
+        GemmArgs a;
+        a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.bias = bias; a.bias2 = bias2; a.R = (const bf16_t*)R; a.ldr = Cout;
+        a.C = (bf16_t*)Y; a.ldc = Cout; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.stride = 1; a.up = 0; a.Hout = Hin; a.Wout = Win;
+        a.M = B * HW; a.N = Cout; a.K = 9 * Cin; a.K1 = a.K; a.zero_page = g_zero_page;
+        a.splitk = sd_conv3x3_splitk(a.M, a.N, Cin, Hin, Win, 1, 0);
+        const size_t slab_bytes = a.splitk > 1 ? (size_t)a.splitk * a.M * a.N * 4 : 0;
+        char* scratch = (char*)op_scratch(slab_bytes + sd_groupnorm_scratch_bytes(B, HW, groups));
+        SD_REQUIRE(scratch, "sd_op_conv3x3_groupnorm: cannot allocate scratch");
+        const bool slab_off = getenv("SD_GN_SLAB") && atoi(getenv("SD_GN_SLAB")) == 0;     // per call: the test compares both
+        if (a.splitk > 1) { a.slab = (float*)scratch; a.defer_reduce = (slab_off || !sd_groupnorm_slab_ok(B, HW, Cout, 0, groups)) ? 0 : 1; }
+        if (int rc = sd_launch_conv3x3(a, (hipStream_t)stream)) return rc;
+        GroupNormArgs g;
+        g.x1 = (const bf16_t*)Y; g.C1 = Cout; g.gamma = gamma; g.beta = beta; g.y = (bf16_t*)Yn; g.B = B; g.HW = HW;
+        g.groups = groups; g.eps = eps; g.silu = silu; g.nsplit = sd_groupnorm_nsplit(B, HW);
+        g.partial = (float*)(scratch + slab_bytes);
+        if (a.defer_reduce) {
+            g.slab = a.slab; g.splitk = a.splitk; g.sbias = bias; g.sbias2 = bias2; g.sR = (const bf16_t*)R; g.sldr = Cout;
+            g.x1w = (bf16_t*)Y;
+        }
+        return sd_launch_groupnorm(g, (hipStream_t)stream);
+    }
+    SD_REQUIRE(HW % 64 == 0, "sd_op_conv3x3_groupnorm: %dx%d pixels per sample: producer statistics come in 64-pixel blocks", Hin, Win);
     const size_t stats_bytes = (size_t)B * (HW / 64) * Cout * 2 * 4;
     char* scratch = (char*)op_scratch(stats_bytes + sd_groupnorm_scratch_bytes(B, HW, groups));
     SD_REQUIRE(scratch, "sd_op_conv3x3_groupnorm: cannot allocate scratch");
@@ -2277,6 +2356,10 @@ extern "C" int sd_op_conv3x3_groupnorm(void* stream, const void* X, const void* 
     g.partial = (float*)(scratch + stats_bytes);
     g.stats1 = (const float*)scratch;
     return sd_launch_groupnorm(g, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_conv3x3_splitk(int M, int Cout, int Cin, int Hin, int Win, int stride, int upsample) {
+    return sd_conv3x3_splitk(M, Cout, Cin, Hin, Win, stride, upsample ? 1 : 0);
 }
 
 extern "C" int sd_op_layernorm(void* stream, const void* x, const float* gamma, const float* beta, void* y, int rows,

@@ -303,6 +303,50 @@ def test_conv3x3_groupnorm_producer_statistics(sdlib, B, H, Cin, Cout):
     assert rel_l2(yn, own) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,res", [
+    (16, 8, 512, 1280, True),      # 8x8: 32 output tiles, split-K 8 on the halo kernel; 3 units per thread, 8 slabs per trip
+    (16, 16, 512, 1280, True),     # 16x16: split-K 2; 10 units per thread, 2 slabs per trip
+    (8, 8, 512, 2560, False),      # 80 channels per group (5 units per thread), split-K 4, no residual
+    (6, 16, 384, 640, True),       # 20 channels per group, split-K 3 (odd: one slab per trip)
+    (3, 4, 256, 1280, True),       # 4x4 images: the implicit-GEMM conv kernel's split-K
+])
+def test_conv3x3_groupnorm_small_images_finish_the_deferred_splitk_reduce(sdlib, B, H, Cin, Cout, res):
+    """The plan's conv -> GroupNorm pair at the 8x8 / 16x16 levels (diffusers ResnetBlock2D: conv1 -> norm2, conv2 -> the next
+    block's norm1): a split-K conv leaves its fp32 partial slabs to the single-launch GroupNorm, which sums them in
+    splitk_reduce_kernel's order, adds bias / time-embedding row / residual, stores the conv output and normalises it -- one
+    launch instead of two.  Bit-identical to conv (+ reduce) followed by the GroupNorm (SD_GN_SLAB=0), and right."""
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = r16(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b, b2 = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    r = r16(torch.randn(B, Cout, H, H, generator=g)) if res else None
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    conv = r16(F.conv2d(x, w, b, padding=1) + b2[None, :, None, None] + (r if res else 0.0))
+    ref = F.silu(F.group_norm(conv, 32, gamma, beta, 1e-5))
+    xd = dev(x.permute(0, 2, 3, 1).contiguous(), torch.bfloat16)
+    wd = dev(w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin // 64, 64).permute(0, 2, 1, 3).contiguous(), torch.bfloat16)
+    rd = dev(r.permute(0, 2, 3, 1).contiguous(), torch.bfloat16) if res else None
+
+    def run():
+        y = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        yn = torch.full_like(y, float("nan"))
+        _lib.check(sdlib.sd_op_conv3x3_groupnorm(stream(), P(xd), P(wd), P(b), P(b2), P(rd) if res else None, P(y), B, H, H, Cin,
+                                                 Cout, P(gamma), P(beta), P(yn), 32, 1e-5, 1))
+        torch.cuda.synchronize()
+        return y, yn
+    assert sdlib.sd_op_conv3x3_splitk(B * H * H, Cout, Cin, H, H, 1, 0) > 1       # the case exists to exercise the slabs
+    y, yn = run()
+    assert rel_l2(y.permute(0, 3, 1, 2), conv) < TOL
+    assert rel_l2(yn.permute(0, 3, 1, 2), ref) < TOL
+    os.environ["SD_GN_SLAB"] = "0"
+    try:
+        y2, yn2 = run()
+    finally:
+        del os.environ["SD_GN_SLAB"]
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    assert torch.equal(yn.view(torch.int16), yn2.view(torch.int16))
+
+
 def fold_layernorm(w, gamma, beta, bias):
     """Host-side packing of a LayerNorm-folded GEMM weight (mirror of the packer's ln_fold in unet.hip)."""
     wg = r16(w * gamma[None, :])

@@ -83,6 +83,46 @@ def test_unet_forward_is_bitwise_reproducible_and_batch_consistent(small_unet):
     assert rel_l2(a, ref) < 2e-3          # different split-K factors reassociate fp32 sums, nothing more
 
 
+def _fused_groupnorms(net, lat, ub):
+    """GroupNorm launches of one forward that finish their producer's deferred split-K reduce (op_times: K column > 0)."""
+    import ctypes as C
+    from sonicdiffusionbayeslab_amd import _lib
+    out = torch.empty(ub, 4, lat.shape[2], lat.shape[3], device="cuda")
+    ws = net._workspace(ub)
+    buf = C.create_string_buffer(1 << 20)
+    n = net._lib.sd_unet_forward_op_times(net._handle, _lib.current_stream(), lat.data_ptr(), lat.shape[0], ub, 501.0, out.data_ptr(),
+                                          net._ws_ptr(ws), ws.numel() - 256, 0, net.cache_branch_id, buf, len(buf))
+    assert n > 0
+    rows = [l.split() for l in buf.value.decode().splitlines()]
+    gn = [r for r in rows if int(r[1]) == 3]
+    return sum(int(r[4]) > 0 for r in gn), len(gn)
+
+
+def test_deferred_splitk_reduce_in_the_single_launch_groupnorm_is_bit_identical(small_unet):
+    """At the 8x8 / 16x16 levels the plan hands the fp32 partial slabs of a split-K conv / GEMM to the single-launch GroupNorm
+    that reads its output first (csrc/unet.hip fuse_deferred_reduce: resnet conv1 -> norm2, conv2 / proj_out / downsampler ->
+    the next block's norm1, incl. the up path's channel concat): same sums in the same order, one launch instead of two.  A second
+    handle built with SD_GN_SLAB=0 (conv + splitk_reduce, then the GroupNorm) must give the same bits."""
+    from sonicdiffusionbayeslab_amd.unet import HipUNet2DConditionModel
+    cfg, sd, net = small_unet
+    lat, pe, ne = synth_inputs(cfg, 2, seed=5)
+    ctx = torch.cat([ne, pe]).cuda()
+    net.set_context(ctx)
+    a = net.forward_latents(lat.cuda(), 4, 501.0).clone()
+    fused, total = _fused_groupnorms(net, lat.cuda(), 4)
+    assert fused >= 8, (fused, total)                  # the pass found its pairs (every resnet below the top level has two)
+    os.environ["SD_GN_SLAB"] = "0"
+    try:
+        plain = HipUNet2DConditionModel(cfg, sd)
+        plain.set_context(ctx)
+        b = plain.forward_latents(lat.cuda(), 4, 501.0).clone()
+        assert _fused_groupnorms(plain, lat.cuda(), 4)[0] == 0
+    finally:
+        del os.environ["SD_GN_SLAB"]
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
+
+
 def test_cfg_prefix_deduplication_matches_explicitly_duplicated_latents(small_unet):
     """A CFG forward (UNet batch = 2 x latent batch: `torch.cat([latents] * 2)` of src/models.py:222) runs everything before
     the first prompt cross-attention once per latent and copies it to both halves; handing the library the duplicated
