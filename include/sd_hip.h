@@ -279,6 +279,13 @@ int sd_op_xattn_fused_rowstats(void* stream, const void* X, const void* R, void*
                                const float* bias, int M, int C, int rows_per_sample, int L, float* rowstats);
 int sd_op_xattn_fused(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
                       const float* bias, int M, int C, int rows_per_sample, int L);
+/* The same with the block's norm2 folded in (how the plan runs it at the 64x64 / 32x32 levels): X holds the UN-normalised rows
+ * (normally X == R), ln_rowstats [ln_parts][ln_rows][2] their (sum, sum of squares) partials (row m reads row m % ln_rows),
+ * At = tiled rows of scale K_h W_q,h diag(gamma) centred over the channel, c2 [samples][640] fp32 the beta term of every key
+ * slot: score = rstd_m (X . At)[m][n] + c2[n].  rowstats: optional partials of Y as in sd_op_xattn_fused_rowstats. */
+int sd_op_xattn_fused_ln(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                         const float* bias, int M, int C, int rows_per_sample, int L, const float* ln_rowstats, int ln_parts,
+                         long long ln_rows, const float* c2, float eps, float* rowstats);
 /* diagnostic twin (tools/xattn_stamps.py; no reference counterpart): same result, and the kernel stores 8 s_memtime
  * stamps per workgroup to `stamps` (caller-owned device memory, 8 * (M / 128) * slices 64-bit words) */
 /* timing ablations of the dominant kernel (the stride-1 3x3 conv with the LDS-resident halo); results are WRONG by design

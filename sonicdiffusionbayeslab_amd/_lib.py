@@ -105,6 +105,7 @@ _SIGS = {
     "sd_op_gemm_ln": (_i, [_vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _f, _vp, _ll, _i, _i, _i, _i]),
     "sd_op_xattn_fused_rowstats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_op_xattn_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "sd_op_xattn_fused_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _ll, _vp, _f, _vp]),
     "sd_op_xattn_fused_stamps": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_op_gemm_fp8": (_i, [_vp, _vp, _ll, _vp, _vp, _f, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f]),
     "sd_op_conv3x3_fp8": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),

@@ -173,6 +173,14 @@ struct XattnArgs {
     const float* bias = nullptr;  // [C] to_out bias
     int M = 0, C = 0, rows_per_sample = 0, L = 0;
     float* rowstats = nullptr;    // [2 * channel slices][M][2]: LayerNorm partials of Y (GemmArgs::rowstats layout), null = off
+    // LayerNorm (norm2) folded into the kernel: X holds the UN-normalised rows (usually X == R), ln_rs = their row partials
+    // [ln_np][ln_rows][2] (sum, sum of squares; GemmArgs::rowstats of the producer; row m reads row m % ln_rows: a CFG pair
+    // replicated after the producer ran shares them), At = rows of  scale K_h W_q,h diag(gamma)  CENTRED over the channel
+    // (sum_c (x_c - mean) w_c = sum_c x_c (w_c - mean_c w): the row mean drops out of the product), ln_c2 [samples][640] fp32 =
+    // the beta term of every key slot.  A score is then  rstd_m * (X . At)[m][n] + ln_c2[n].  null = X is already normalised.
+    const float* ln_rs = nullptr; int ln_np = 0; long ln_rows = 0;
+    const float* ln_c2 = nullptr;
+    float ln_eps = 1e-5f;
     unsigned long long* stamps = nullptr;   // diagnostic: 8 s_memtime stamps per workgroup (SD_XATTN_STAMPS), else null
 };
 bool sd_xattn_fused_applicable(int rows_per_sample, int C, int heads, int L);

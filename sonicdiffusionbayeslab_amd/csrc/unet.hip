@@ -187,7 +187,7 @@ struct Plan {
     std::vector<int> ctx_c;               // C per layer
     int ctx_bf16 = -1;                    // bf16 copy of encoder_hidden_states
     // folded prompt cross-attention (per layer): A^T [UB][heads*80][C] and B [UB][C][heads*80], see transformer()
-    struct Fold { int kv, at, bw, C; size_t wqT, wo; bool perm; };   // perm: Bw in the fused kernel's k order
+    struct Fold { int kv, at, bw, C; size_t wqT, wo; bool perm; int c2 = -1; size_t lnu = NOFF; };   // perm: Bw in the fused kernel's k order; c2 >= 0: norm2 folded (wqT = the .ln weights, c2 = tensor of the beta terms)
     std::vector<Fold> ctx_fold;
     int ctx_fold_scratch = -1;            // masked K / V expansions [2][UB][heads*80][Cmax]
     std::map<std::string, int> taps;
@@ -743,6 +743,29 @@ struct Packer {
             for (int r = 0; r < c; ++r)
                 for (int k = 0; k < c; ++k) o[(size_t)r * c + k] = f32_to_bf16_host(d[(size_t)k * c + r]);
         }
+        if (!u->fp8) {
+            // norm2 folded into the fused cross-attention (XattnArgs::ln_rs): A^T = (scale K_h) . W with
+            //   W[c][j] = W_q[j][c] gamma[c] - (1 / C) sum_c' W_q[j][c'] gamma[c']      (rows c of the ".T" layout, CENTRED over c:
+            //   sum_c (x_c - mean) w_c = sum_c x_c (w_c - mean_c w), so the kernel never needs the row mean), and
+            //   u[j] = sum_c W_q[j][c] beta[c]: the beta term of key slot n is  (scale K_h[n]) . u  (set_context, fp32)
+            const auto& d = P(t + "attn2.to_q.weight");
+            const auto& gm = P(t + "norm2.weight");
+            const auto& bt = P(t + "norm2.bias");
+            size_t off = alloc(t + "attn2.to_q.weight.T.ln", d.size() * 2);
+            size_t uoff = alloc(t + "attn2.to_q.lnu", (size_t)c * 4);
+            unsigned short* o = (unsigned short*)(u->hblob.data() + off);
+            float* uu = (float*)(u->hblob.data() + uoff);
+            for (int j = 0; j < c; ++j) {
+                double m = 0.0, ub = 0.0;
+                for (int cc = 0; cc < c; ++cc) {
+                    m += (double)d[(size_t)j * c + cc] * gm[cc];
+                    ub += (double)d[(size_t)j * c + cc] * bt[cc];
+                }
+                m /= c;
+                uu[j] = (float)ub;
+                for (int cc = 0; cc < c; ++cc) o[(size_t)cc * c + j] = f32_to_bf16_host((float)((double)d[(size_t)j * c + cc] * gm[cc] - m));
+            }
+        }
         concat_rows(t + "attn2.kv.weight", {t + "attn2.to_k.weight", t + "attn2.to_v.weight"});
         bf16_same(t + "attn2.to_out.0.weight"); f32(t + "attn2.to_out.0.bias");
         geglu(t, c);
@@ -1122,6 +1145,7 @@ struct Builder {
         }
         pl.ops.back().qps = 1;          // W_q of attn1 carries the scale (Packer::transformer)
         int h1 = gemm(a1, C, -1, 0, M, C, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", h0, 0);
+        const int to_out_op = (int)pl.ops.size() - 1;
         if (prefix_rep > 1) {        // end of the prompt-independent prefix: both CFG halves continue from copies
             x = replicate(x, (size_t)M * C * 2, prefix_rep);
             h1 = replicate(h1, (size_t)M * C * 2, prefix_rep);
@@ -1129,7 +1153,16 @@ struct Builder {
             M = UB * hw;
             prefix_rep = 1;
         }
-        int n2 = ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
+        // norm2: folded into the fused cross-attention where that runs and attn1.to_out can deliver the row partials
+        // (SD_XATTN_LN=0: the separate LayerNorm launch); otherwise a LayerNorm launch (created below, when it is known)
+        static const int fused_min_hw0 = getenv("SD_XATTN_FUSED") ? atoi(getenv("SD_XATTN_FUSED")) : 1024;
+        static const bool xln_off = getenv("SD_XATTN_LN") && atoi(getenv("SD_XATTN_LN")) == 0;
+        int rs2 = -1, np2 = 0;
+        const long rs2_rows = (long)pl.ops[to_out_op].M;
+        if (!fq && !xln_off && fused_min_hw0 > 0 && hw >= fused_min_hw0 && sd_xattn_fused_applicable(hw, C, u->cfg.num_heads, L) &&
+            u->woff.count(t + "attn2.to_q.weight.T.ln"))
+            np2 = want_rowstats(pl.ops[to_out_op], (int)rs2_rows, C, rs2);
+        int n2 = np2 > 0 ? h1 : ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
         // K|V of the prompt: projected once per sampling run by sd_unet_set_context
         int kv = ctx_tensor((size_t)UB * L * 2 * C * 2);
         pl.ctx_kv.push_back(kv);
@@ -1149,9 +1182,12 @@ struct Builder {
         const int NH = u->cfg.num_heads, NP = NH * 80;
         if (fused_min_hw > 0 && hw >= fused_min_hw && sd_xattn_fused_applicable(hw, C, NH, L)) {
             int at = ctx_tensor((size_t)UB * NP * C * 2), bw = ctx_tensor((size_t)UB * C * NP * 2);
-            pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight"), true});
+            Plan::Fold fd{kv, at, bw, C, W(t + (np2 > 0 ? "attn2.to_q.weight.T.ln" : "attn2.to_q.weight.T")), W(t + "attn2.to_out.0.weight"), true};
+            if (np2 > 0) { fd.c2 = ctx_tensor((size_t)UB * NP * 4); fd.lnu = W(t + "attn2.to_q.lnu"); }
+            pl.ctx_fold.push_back(fd);
             Op o; o.kind = OP_XATTN; o.x1 = n2; o.r = h1; o.wt = at; o.x2 = bw; o.M = M; o.N = C; o.K = NP; o.rpb = hw;
             o.sm_valid = L; o.b = W(t + "attn2.to_out.0.bias"); o.heads = NH;
+            if (np2 > 0) { o.lnrs = rs2; o.lnnp = np2; o.s1 = fd.c2; o.ldx_o = rs2_rows; }   // (s1: the c2 tensor; ldx_o: rows of the partials)
             o.out = tensor((size_t)M * C * 2); push(o); h2 = o.out;
         } else if (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) {
             int at = ctx_tensor((size_t)UB * NP * C * 2), bw = ctx_tensor((size_t)UB * C * NP * 2);
@@ -1625,6 +1661,9 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.At = (const bf16_t*)T(o.wt); a.Bw = (const bf16_t*)T(o.x2); a.bias = (const float*)(wb + o.b);
             a.M = o.M; a.C = o.N; a.rows_per_sample = o.rpb; a.L = o.sm_valid;
             a.rowstats = (float*)T(o.rs);
+            if (o.lnrs >= 0) {      // norm2 folded in: X = the un-normalised residual stream
+                a.ln_rs = (const float*)T(o.lnrs); a.ln_np = o.lnnp; a.ln_rows = o.ldx_o; a.ln_c2 = (const float*)T(o.s1); a.ln_eps = 1e-5f;
+            }
             return sd_launch_xattn_fused(a, stream);
         }
         case OP_REPLICATE:
@@ -1886,6 +1925,10 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
             a.zero_page = g_zero_page;
             if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
             if (f.perm && (rc = sd_launch_retile32(tmp, at_dst, unet_batch, NP, C, NP, (hipStream_t)stream))) return rc;
+        }
+        if (f.c2 >= 0) {    // beta term of every key slot: c2[sample][slot] = (scale K_h[slot]) . u   (fp32 GEMV over the expanded rows)
+            if ((rc = sd_launch_gemv((const float*)(u->dweights + f.lnu), kexp, nullptr, (float*)(ws + pl.tensors[f.c2].off),
+                                     unet_batch * NP, C, 0, (hipStream_t)stream))) return rc;
         }
         {   // B^T [UB*NP, C] = V_masked . W_o^T (one GEMM, into the K expansion's scratch), then transposed per sample
             // to [C, NP]: K-contiguous over (head, key) -> W operand of GEMM 2
@@ -2548,6 +2591,19 @@ extern "C" int sd_op_xattn_fused(void* stream, const void* X, const void* R, voi
     XattnArgs a;
     a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
     a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L;
+    return sd_launch_xattn_fused(a, (hipStream_t)stream);
+}
+
+// norm2 folded in (XattnArgs::ln_rs): X = the un-normalised rows, At = the CENTRED gamma-scaled operand, c2 [samples][640] fp32
+extern "C" int sd_op_xattn_fused_ln(void* stream, const void* X, const void* R, void* Y, const void* At, const void* Bw,
+                                    const float* bias, int M, int C, int rows_per_sample, int L, const float* ln_rowstats,
+                                    int ln_parts, long long ln_rows, const float* c2, float eps, float* rowstats) {
+    SD_REQUIRE(sd_xattn_fused_applicable(rows_per_sample, C, 8, L), "sd_op_xattn_fused_ln: shape not supported");
+    SD_REQUIRE(ln_rowstats && c2, "sd_op_xattn_fused_ln: null operand");
+    XattnArgs a;
+    a.X = (const bf16_t*)X; a.R = (const bf16_t*)R; a.Y = (bf16_t*)Y; a.At = (const bf16_t*)At; a.Bw = (const bf16_t*)Bw;
+    a.bias = bias; a.M = M; a.C = C; a.rows_per_sample = rows_per_sample; a.L = L; a.rowstats = rowstats;
+    a.ln_rs = ln_rowstats; a.ln_np = ln_parts; a.ln_rows = ln_rows; a.ln_c2 = c2; a.ln_eps = eps;
     return sd_launch_xattn_fused(a, (hipStream_t)stream);
 }
 

@@ -57,6 +57,10 @@ constexpr int ROFF = NSTAGE * STAGE2;       // 120 KiB
 constexpr int EXOFF = STAGE2;               // P exchange buffer: 8 waves x 10 KiB behind phase-2 stage 0
 constexpr int MAXC = 1280;
 constexpr int BIASOFF = ROFF + 2 * RTILE;   // 152 KiB
+constexpr int C2OFF = RING;                 // V & 32: ln_c2 of the sample (2.5 KiB + DMA slack) and the token blocks' rstd (512 B) in
+constexpr int RSOFF = C2OFF + 3072;         // the 8 KiB between the phase-1 ring and the bias: phase 2 reaches them (second residual
+                                            // tile) only after the exchange barriers, when every wave is past the softmax
+static_assert(RSOFF + TOK * 4 <= BIASOFF, "LDS budget (LayerNorm fold)");
 constexpr int SMEM = BIASOFF + MAXC * 4;    // 157 KiB
 static_assert(RING <= BIASOFF && EXOFF + 8 * 10240 <= ROFF && SMEM <= 160 * 1024, "LDS budget");
 constexpr int PIECES = 6;                   // 1-KiB DMA pieces per wave and stage, both phases
@@ -81,6 +85,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 //          halves in the other order (fp32 reassociation: not bit-identical with bit 3 clear).
 //   bit 2  the to_out bias reaches LDS by LDS-DMA with the first stage instead of ordinary loads + a full wait in front
 //          of the first DMA piece (the first operand tile used to land ~5 k cycles into the workgroup).
+//   bit 5  norm2 folded in (XattnArgs::ln_rs): X is the un-normalised residual stream, the row's rstd comes from its producer's
+//          partials (16 loads per lane in the prologue, in flight under the first two operand tiles) and the beta term of every
+//          key slot from LDS; a score is rstd * raw + c2 -- one FMA per score in the softmax, and the LayerNorm launch with
+//          its 2 x M x C x 2 bytes is gone.
 template <int V>
 __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,6 +122,15 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     // multiple of 64, a partial last piece re-reads the vector's tail -- clamped source, identical bytes land in the slack
     // behind sbias[C]); else ordinary loads, the kernel's only ones, retired before any DMA is in flight.
     float* sbias = (float*)(smem + BIASOFF);
+    float* sc2 = (float*)(smem + C2OFF);
+    float* srstd = (float*)(smem + RSOFF);
+    f32x2_t lnp[16];
+    if (V & 32) {       // this lane's token: row partials of the producer (consumed below, after the first DMA pieces are issued)
+        const long lrow = (m0 + 32 * tb + r) % p.ln_rows;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            lnp[i] = *(const f32x2_t*)(p.ln_rs + ((long)(i < p.ln_np ? i : 0) * p.ln_rows + lrow) * 2);
+    }
     if (V & 4) {
         if (wave * 256 < C) {
             const int i = min(wave * 256 + lane * 4, C - 4);
@@ -121,6 +138,12 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
         }
     } else {
         for (int i = tid; i < C; i += 512) sbias[i] = p.bias[i];
+    }
+    if (V & 32) {       // ln_c2 of this sample: 640 floats = 2.5 one-KiB pieces (waves 0..2; the third clamps its source)
+        if (wave < 3) {
+            const int i = min(wave * 256 + lane * 4, KEYS - 4);
+            glds16(p.ln_c2 + (long)sample * KEYS + i, (char*)sc2 + wave * 1024);
+        }
     }
 
     // ---- LDS-DMA pieces (16 rows x 64 B; lane -> row lane >> 2, chunk lane & 3, swizzled on the source) ----
@@ -169,6 +192,16 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
     for (int i = 0; i < PIECES; ++i) piece1(0, i, smem, true);
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) piece1(1, i, smem + STAGE1, KT > 1);
+    if (V & 32) {       // rstd of this lane's token -> LDS (no register held through phase 1); read back in the softmax
+        float ls = 0.f, lq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ls += i < p.ln_np ? lnp[i][0] : 0.f;
+            lq += i < p.ln_np ? lnp[i][1] : 0.f;
+        }
+        const float mean = ls / (float)C;
+        srstd[32 * tb + r] = rsqrtf(fmaxf(lq / (float)C - mean * mean, 0.f) + p.ln_eps);      // (both lane halves: same value)
+    }
 
     // =============================== phase 1: S^T = A^T . X^T (this wave's 4 heads) ===============================
     // V & 16: no zeroing of the 160 accumulators -- the first K tile's first k-step multiplies onto a constant-zero C operand
@@ -275,6 +308,16 @@ __global__ __launch_bounds__(512, 2) void xattn_fused_kernel(const XattnArgs p) 
             const int u = 5 * hd + q;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[q * 8 + j] = S[u >> 1][(u & 1) * 8 + j];
+        }
+        if (V & 32) {   // score = rstd(token) * raw + c2(key slot); slot of v[8 q + j] = 16 q + 8 (j >> 2) + 4 h + (j & 3)
+            const float rstd = srstd[32 * tb + r];
+            const float* c2h = sc2 + (4 * hg + hd) * 80 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const f32x4 cv = *(const f32x4*)(c2h + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * q + j] = __builtin_fmaf(v[4 * q + j], rstd, cv[j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -505,12 +548,20 @@ int sd_launch_xattn_fused(const XattnArgs& a, hipStream_t stream) {
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<31>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        SD_CHECK_HIP(hipFuncSetAttribute((const void*)xattn_fused_kernel<63>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     // SD_XATTN_VARIANT=0: the round-2 kernel (A/B); 15 = the first four round-3 changes; default 31 = all round-3 changes (measured one by one on one box, 64x64
     // launch of the bench: 72.2 us -> bias by DMA 70.9 -> + phase-1 carried group 69.9 -> + phase 2 68.5 -> + static P 68.0)
     static const int variant = getenv("SD_XATTN_VARIANT") ? atoi(getenv("SD_XATTN_VARIANT")) : 31;
     const int wgs = a.M / TOK, nsl = sd_xattn_slices(a.M, a.C);
+    if (a.ln_rs) {      // norm2 folded in: the product variant only
+        SD_REQUIRE(a.ln_c2 && a.ln_np >= 1 && a.ln_np <= 16 && a.ln_rows > 0 && a.M % a.ln_rows == 0 && a.ln_eps > 0.f && !a.stamps,
+                   "xattn with the LayerNorm fold: 1..16 row partials, M a multiple of the partials' rows, c2");
+        hipLaunchKernelGGL(xattn_fused_kernel<63>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
+        SD_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (variant == 0) hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     else if (variant == 15) hipLaunchKernelGGL(xattn_fused_kernel<15>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);
     else hipLaunchKernelGGL(xattn_fused_kernel<31>, dim3(wgs, nsl), dim3(512), SMEM, stream, a);

@@ -923,3 +923,77 @@ def test_xattn_fused(sdlib, B, hw, C, spike):
     o64 = out.double().cpu()
     assert torch.allclose(tot[:, 0].double(), o64.sum(1), rtol=1e-4, atol=1e-2)
     assert torch.allclose(tot[:, 1].double(), (o64 * o64).sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,hw,C,offset,dup", [(2, 256, 320, 0.0, False), (1, 1024, 640, 1.5, False), (2, 128, 1280, 0.5, False),
+                                               (4, 4096, 320, 1.0, True)])
+def test_xattn_fused_with_norm2_folded(sdlib, B, hw, C, offset, dup):
+    """The block's norm2 folded into the fused cross-attention (diffusers BasicTransformerBlock: attn2(norm2(h)) + h, reached
+    from src/models.py:227-235): the kernel reads the UN-normalised rows, takes rstd of a row from its producer's (sum, sum of
+    squares) partials, and the operand A is scaled by gamma and CENTRED over the channel so that the row mean drops out
+    (sum_c (x_c - m) w_c = sum_c x_c (w_c - mean(w))); the beta term is a per-key-slot constant c2.  Against (i) the same
+    formula in fp64 from the rounded operands and (ii) LayerNorm + F.scaled_dot_product_attention + linears.  offset: rows
+    with |mean| ~ sigma (the centring carries the whole subtraction); dup: a CFG pair replicated after the producer ran
+    (row m reads partials row m % ln_rows)."""
+    g = torch.Generator().manual_seed(B * 1000 + hw + C + 7)
+    H, L, d = 8, 77, C // 8
+    Bu = B // 2 if dup else B                  # distinct samples of rows
+    M, Mu = B * hw, Bu * hw
+    xu = r16(torch.randn(Mu, C, generator=g) * 0.7 + offset + 0.3 * torch.randn(Mu, 1, generator=g))
+    x = torch.cat([xu, xu]) if dup else xu
+    r = r16(torch.randn(M, C, generator=g))
+    gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    wq, wo = (torch.randn(C, C, generator=g) / math.sqrt(C) for _ in range(2))
+    wk, wv = (torch.randn(C, 768, generator=g) / math.sqrt(768) for _ in range(2))
+    bo = torch.randn(C, generator=g)
+    ctx = torch.randn(B, L, 768, generator=g)
+    ctx[0, 5] *= 4.0
+    K, V = ctx @ wk.t(), ctx @ wv.t()
+    scale = 1.0 / math.sqrt(d)
+    At = torch.zeros(B, H * 80, C, dtype=torch.float64)
+    Bn = torch.zeros(B, H * 80, C)
+    for hh in range(H):
+        sl = slice(hh * d, (hh + 1) * d)
+        At[:, hh * 80: hh * 80 + L] = (scale * K[:, :, sl] @ wq[sl, :]).double()
+        Bn[:, hh * 80: hh * 80 + L] = V[:, :, sl] @ wo[:, sl].t()
+    Ag = At * gamma.double()
+    At_ln = r16((Ag - Ag.mean(-1, keepdim=True)).float())
+    c2 = (At @ beta.double()).float().contiguous()                    # [B, 640]
+    Bn = r16(Bn)
+    # row partials of the producer: (sum, sum of squares) of every 80-column slice
+    parts = 2 * ((C + 159) // 160)
+    xs64 = xu.double().view(Mu, C // 80, 80)
+    rs = torch.stack([xs64.sum(-1), (xs64 * xs64).sum(-1)], -1).permute(1, 0, 2).float().contiguous()     # [parts][Mu][2]
+    assert rs.shape[0] == parts
+    mean = x.double().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.double().var(-1, unbiased=False, keepdim=True) + 1e-5)
+    # (i) the kernel's formula in fp64 from the rounded operands
+    S = (rstd * torch.einsum("bmc,bkc->bmk", x.double().view(B, hw, C), At_ln.double()).view(M, H * 80)
+         + c2.double().repeat_interleave(hw, 0)).view(B, hw, H, 80)
+    S[..., L:] = float("-inf")
+    Pm = torch.softmax(S, dim=-1).view(B, hw, H * 80).float()
+    ref_fold = (r.view(B, hw, C) + torch.einsum("bmk,bkc->bmc", Pm, Bn) + bo).view(M, C)
+    # (ii) LayerNorm, then the unfolded attention
+    xn = (((x.double() - mean) * rstd) * gamma.double() + beta.double()).float().view(B, hw, C)
+    q = (xn @ wq.t()).view(B, hw, H, d).transpose(1, 2)
+    kk, vv = (t.view(B, L, H, d).transpose(1, 2) for t in (K, V))
+    o = F.scaled_dot_product_attention(q, kk, vv).transpose(1, 2).reshape(B, hw, C)
+    ref_attn = (r.view(B, hw, C) + o @ wo.t() + bo).view(M, C)
+    slot = torch.arange(H * 80)
+    perm = (slot & ~12) | ((slot & 4) << 1) | ((slot & 8) >> 1)
+    Bw = torch.zeros(B, C, H * 80)
+    Bw[:, :, perm] = Bn.transpose(1, 2)
+    At_t = At_ln.view(B, H * 80, C // 32, 32).permute(0, 2, 1, 3).contiguous()
+    Bw_t = Bw.view(B, C // 32, 32, 20, 32).permute(0, 1, 3, 2, 4).contiguous()
+    out = torch.full((M, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    oparts = sdlib.sd_op_ln_partials(1, M, C)
+    ors = torch.full((oparts, M, 2), float("nan"), device="cuda")
+    _lib.check(sdlib.sd_op_xattn_fused_ln(stream(), P(x, torch.bfloat16), P(r, torch.bfloat16), P(out), P(At_t, torch.bfloat16),
+                                          P(Bw_t, torch.bfloat16), P(bo), M, C, hw, L, P(rs), parts, Mu, P(c2), 1e-5, P(ors)))
+    torch.cuda.synchronize()
+    e1, e2 = rel_l2(out, ref_fold), rel_l2(out, ref_attn)
+    print(f"xattn fused + norm2 B={B} hw={hw} C={C} offset={offset}: vs folded fp64 {e1:.3e}, vs LayerNorm + SDPA + linears {e2:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert e1 < 8e-3 and e2 < 2e-2
+    tot = ors.sum(0).cpu()
+    assert torch.allclose(tot[:, 0].double(), out.double().cpu().sum(1), rtol=1e-4, atol=1e-2)
