@@ -6,6 +6,7 @@ import torch
 from sonicdiffusionbayeslab_amd import _lib
 
 B, hw, C = (int(x) for x in (sys.argv[1:4] or (16, 4096, 320)))
+LN = len(sys.argv) > 4 and sys.argv[4] == "ln"      # the product variant of round 5: norm2 folded in (no stamp entry point)
 M = B * hw
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
@@ -19,6 +20,16 @@ nwg = M // 128 * 4
 stamps = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
 call = lambda: _lib.check(lib.sd_op_xattn_fused(st, x.data_ptr(), r.data_ptr(), y.data_ptr(), at.data_ptr(), bw.data_ptr(),
                                                 bias.data_ptr(), M, C, hw, 77))
+if LN:
+    parts = 2 * ((C + 159) // 160)
+    xs = x.float().view(M, C // 80, 80)
+    rs = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).contiguous()
+    c2 = torch.randn(B, 640, device="cuda")
+    oparts = lib.sd_op_ln_partials(1, M, C)
+    ors = torch.empty(oparts, M, 2, device="cuda")
+    call = lambda: _lib.check(lib.sd_op_xattn_fused_ln(st, x.data_ptr(), x.data_ptr(), y.data_ptr(), at.data_ptr(), bw.data_ptr(),
+                                                       bias.data_ptr(), M, C, hw, 77, rs.data_ptr(), parts, M, c2.data_ptr(), 1e-5,
+                                                       ors.data_ptr()))
 for _ in range(3):
     call()
 torch.cuda.synchronize()
@@ -27,7 +38,9 @@ s.record()
 for _ in range(10):
     call()
 e.record(); torch.cuda.synchronize()
-print(f"B={B} hw={hw} C={C}: {s.elapsed_time(e) / 10 * 1e3:.1f} us per launch (no stamps)")
+print(f"B={B} hw={hw} C={C}: {s.elapsed_time(e) / 10 * 1e3:.1f} us per launch (no stamps{', norm2 folded, X == R, row partials out' if LN else ''})")
+if LN:
+    sys.exit(0)
 _lib.check(lib.sd_op_xattn_fused_stamps(st, x.data_ptr(), r.data_ptr(), y.data_ptr(), at.data_ptr(), bw.data_ptr(),
                                         bias.data_ptr(), M, C, hw, 77, stamps.data_ptr()))
 torch.cuda.synchronize()
