@@ -200,6 +200,13 @@ int sd_op_gemm(void* stream, const void* X, long long ldx, const void* X2, long 
 int sd_op_gemm_batched(void* stream, const void* X, long long ldx, const void* W, long long w_batch_stride,
                        int rows_per_batch, const float* bias, const void* R, long long ldr, void* C, long long ldc,
                        int M, int N, int K, int epi, int sm_valid);
+/* The softmax form (epi 2) with the block's norm2 folded in -- the first GEMM of the two-GEMM prompt cross-attention at the
+ * 16x16 level: X = un-normalised rows, W = per-sample operands scaled by gamma, c1 / c2 = per-sample [N] fp32 vectors (row
+ * sums of the rounded W; beta term), rowstats [parts][M][2] = (sum, sum of squares) partials of X's rows:
+ * P = softmax over every 80-column group of  rstd_m * (X W^T - mean_m * c1) + c2. */
+int sd_op_gemm_batched_softmax_ln(void* stream, const void* X, long long ldx, const void* W, long long w_batch_stride,
+                                  int rows_per_batch, void* C, long long ldc, int M, int N, int K, int sm_valid,
+                                  const float* rowstats, int parts, const float* c1, const float* c2, float eps);
 /* NHWC 3x3 conv, pad 1, stride 1|2, optional fused nearest-2x upsample; W is bf16
  * [Cout][Cin/64][3*3][64] (K runs over 64-channel slice, tap, channel) */
 int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2, const void* R,

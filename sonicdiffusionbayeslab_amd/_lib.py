@@ -83,6 +83,7 @@ _SIGS = {
     "sd_sched_step": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_f), _ll]),
     "sd_op_gemm": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i]),
     "sd_op_gemm_batched": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i]),
+    "sd_op_gemm_batched_softmax_ln": (_i, [_vp, _vp, _ll, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f]),
     "sd_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "sd_op_conv3x3_ablate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "sd_op_conv3x3_upsample_subpixel": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),

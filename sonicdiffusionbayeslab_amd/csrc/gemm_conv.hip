@@ -272,8 +272,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     //    every later LDS-DMA: retired in order long before the epilogue) -> no latency left in the epilogue;
     //  * GEGLU (the 256 x 256 tile has no register to spare): four partials at a time in the epilogue, the first four
     //    together with the c1 / bias vectors.
-    constexpr bool LN_OK = (EPI == EPI_STD || EPI == EPI_GEGLU) && AMODE == AMODE_GEMM && WTM == 64 && !DT && STAGES == 2;
-    constexpr bool LN_PRE = LN_OK && EPI == EPI_STD;
+    // (EPI_SOFTMAX, round 5: norm2 folded into the first GEMM of the two-GEMM prompt cross-attention -- per-sample weights, so c1 / c2
+    // are per-sample vectors too: GemmArgs::ln_per_sample)
+    constexpr bool LN_OK = (EPI == EPI_STD || EPI == EPI_GEGLU || EPI == EPI_SOFTMAX) && AMODE == AMODE_GEMM && WTM == 64 && !DT && STAGES == 2;
+    constexpr bool LN_PRE = LN_OK && EPI != EPI_GEGLU;
     constexpr int LN_MAXP = 16;
     char* lnbuf = smem + STAGES * STAGE_BYTES + wave * 512;
     // c1 | c2 of this N-wave's WTN columns, fetched by LDS-DMA under the first K tile (waves wm == 0; the K loop's own
@@ -283,8 +285,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(const Ge
     auto ln_vec_dma = [&]() {
         if (wave % WAVES_M == 0 && lane < WTN / 4) {
             const int n = min(n0 + (wave / WAVES_M) * WTN + lane * 4, p.N - 4);
-            glds16(p.ln_c1 + n, lnvec);
-            glds16(p.bias + n, lnvec + WTN * 4);
+            const long vo = (p.ln_per_sample && p.rows_per_batch > 0) ? (long)(m0 / p.rows_per_batch) * p.N : 0;
+            glds16(p.ln_c1 + vo + n, lnvec);
+            glds16(p.bias + vo + n, lnvec + WTN * 4);
         }
     };
     auto ln_issue = [&](int i0, int cnt) {           // partials i0 .. i0 + cnt - 1 of this lane's row -> lnp[0 ..]
@@ -793,7 +796,7 @@ static int check_headmajor(const GemmArgs& a, int epi) {
 static int check_ln(const GemmArgs& a, int epi) {
     if (a.rowstats) SD_REQUIRE(epi == EPI_STD && !(a.splitk > 1 && a.slab), "LayerNorm partials: plain epilogue without split-K");
     if (!a.ln_rs) return 0;
-    SD_REQUIRE((epi == EPI_STD || epi == EPI_GEGLU) && a.dt == 0 && !(a.splitk > 1 && a.slab) && a.ln_c1 && a.ln_np > 0 &&
+    SD_REQUIRE((epi == EPI_STD || epi == EPI_GEGLU || epi == EPI_SOFTMAX) && a.dt == 0 && !(a.splitk > 1 && a.slab) && a.ln_c1 && a.ln_np > 0 &&
                a.ln_np <= 16 && a.X2 == nullptr && a.K1 == a.K && a.K >= 128 && big_tile_mode() == 0 && a.bias && !a.R && !a.bias2,
                "LayerNorm fold: bf16 operands, std / GEGLU epilogue, one K segment, no split-K (epi=%d np=%d)", epi, a.ln_np);
     return 0;
@@ -836,8 +839,9 @@ int sd_launch_gemm(const GemmArgs& a, int epi, hipStream_t stream) {
     SD_REQUIRE(a.rows_per_batch == 0 || a.rows_per_batch % 128 == 0,
                "gemm: rows_per_batch=%d must be a multiple of the 128-row tile", a.rows_per_batch);
     if (epi == EPI_SOFTMAX) {
-        SD_REQUIRE(a.N % 80 == 0 && a.sm_valid > 0 && a.sm_valid <= 80 && a.R == nullptr && a.bias == nullptr,
+        SD_REQUIRE(a.N % 80 == 0 && a.sm_valid > 0 && a.sm_valid <= 80 && a.R == nullptr && (a.bias == nullptr || a.ln_rs),
                    "softmax gemm: N=%d must be a multiple of 80, 0 < sm_valid=%d <= 80, no bias/residual", a.N, a.sm_valid);
+        SD_REQUIRE(!a.ln_per_sample || (a.ln_rs && a.rows_per_batch > 0), "gemm: per-sample LayerNorm vectors need per-sample weights");
         return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_SOFTMAX>(a, stream);
     }
     if (a.rows_per_batch) return launch<128, 160, 2, 2, 2, AMODE_GEMM, EPI_STD>(a, stream);   // tiles must not straddle samples

@@ -58,6 +58,7 @@ struct GemmArgs {
     const float* ln_c1 = nullptr;
     int ln_np = 0;
     float ln_eps = 1e-5f;
+    int ln_per_sample = 0;            // per-sample weights (rows_per_batch > 0): ln_c1 and bias (c2) are [samples][N] as well
     // fp8-e4m3 operands (dt = 1): X and W hold OCP e4m3 bytes, K (and ldx / ldw / Cin) count fp8 elements and are
     // multiples of 128; the epilogue multiplies the fp32 sums by wscale[n] * xscale_inv before bias / residual.
     int dt = 0;

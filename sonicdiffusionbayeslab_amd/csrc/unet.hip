@@ -187,7 +187,7 @@ struct Plan {
     std::vector<int> ctx_c;               // C per layer
     int ctx_bf16 = -1;                    // bf16 copy of encoder_hidden_states
     // folded prompt cross-attention (per layer): A^T [UB][heads*80][C] and B [UB][C][heads*80], see transformer()
-    struct Fold { int kv, at, bw, C; size_t wqT, wo; bool perm; int c2 = -1; size_t lnu = NOFF; };   // perm: Bw in the fused kernel's k order; c2 >= 0: norm2 folded (wqT = the .ln weights, c2 = tensor of the beta terms)
+    struct Fold { int kv, at, bw, C; size_t wqT, wo; bool perm; int c2 = -1; size_t lnu = NOFF; int c1 = -1; size_t ones = NOFF; };   // perm: Bw in the fused kernel's k order; c2 >= 0: norm2 folded (wqT = the .ln weights, c2 = tensor of the beta terms)
     std::vector<Fold> ctx_fold;
     int ctx_fold_scratch = -1;            // masked K / V expansions [2][UB][heads*80][Cmax]
     std::map<std::string, int> taps;
@@ -753,6 +753,8 @@ struct Packer {
             const auto& bt = P(t + "norm2.bias");
             size_t off = alloc(t + "attn2.to_q.weight.T.ln", d.size() * 2);
             size_t uoff = alloc(t + "attn2.to_q.lnu", (size_t)c * 4);
+            size_t ooff = alloc(t + "attn2.to_q.ones", (size_t)c * 4);      // (x of the GEMV that sums the rounded rows of A^T: c1)
+            for (int j = 0; j < c; ++j) ((float*)(u->hblob.data() + ooff))[j] = 1.0f;
             unsigned short* o = (unsigned short*)(u->hblob.data() + off);
             float* uu = (float*)(u->hblob.data() + uoff);
             for (int j = 0; j < c; ++j) {
@@ -766,6 +768,8 @@ struct Packer {
                 for (int cc = 0; cc < c; ++cc) o[(size_t)cc * c + j] = f32_to_bf16_host((float)((double)d[(size_t)j * c + cc] * gm[cc] - m));
             }
         }
+        if (!u->fp8)      // ... and into the plain to_q GEMM of the levels that run the 77-key flash kernel (the 8x8 level at UNet batch 16)
+            ln_fold(t + "attn2.to_q.weight", P(t + "attn2.to_q.weight").data(), c, c, P(t + "norm2.weight"), P(t + "norm2.bias"), nullptr);
         concat_rows(t + "attn2.kv.weight", {t + "attn2.to_k.weight", t + "attn2.to_v.weight"});
         bf16_same(t + "attn2.to_out.0.weight"); f32(t + "attn2.to_out.0.bias");
         geglu(t, c);
@@ -1114,6 +1118,7 @@ struct Builder {
         return conv3(t3, res, cout, cout, 1, 0, p + "conv2.weight", p + "conv2.bias", 0, -1, sc, fq);
     }
     // Transformer2DModel with one BasicTransformerBlock (A.4)
+    int n_transformers = 0;
     int transformer(const std::string& p, int x, int C, int res) {
         const int hw = res * res, L = u->cfg.context_len;
         int M = UB * hw;
@@ -1153,22 +1158,6 @@ struct Builder {
             M = UB * hw;
             prefix_rep = 1;
         }
-        // norm2: folded into the fused cross-attention where that runs and attn1.to_out can deliver the row partials
-        // (SD_XATTN_LN=0: the separate LayerNorm launch); otherwise a LayerNorm launch (created below, when it is known)
-        static const int fused_min_hw0 = getenv("SD_XATTN_FUSED") ? atoi(getenv("SD_XATTN_FUSED")) : 1024;
-        static const bool xln_off = getenv("SD_XATTN_LN") && atoi(getenv("SD_XATTN_LN")) == 0;
-        int rs2 = -1, np2 = 0;
-        const long rs2_rows = (long)pl.ops[to_out_op].M;
-        if (!fq && !xln_off && fused_min_hw0 > 0 && hw >= fused_min_hw0 && sd_xattn_fused_applicable(hw, C, u->cfg.num_heads, L) &&
-            u->woff.count(t + "attn2.to_q.weight.T.ln"))
-            np2 = want_rowstats(pl.ops[to_out_op], (int)rs2_rows, C, rs2);
-        int n2 = np2 > 0 ? h1 : ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
-        // K|V of the prompt: projected once per sampling run by sd_unet_set_context
-        int kv = ctx_tensor((size_t)UB * L * 2 * C * 2);
-        pl.ctx_kv.push_back(kv);
-        pl.ctx_w.push_back(W(t + "attn2.kv.weight"));
-        pl.ctx_c.push_back(C);
-        int h2;
         // Prompt cross-attention.  The prompt is step-invariant, so per sample and head
         //   A_h = scale * W_q,h^T K_h^T  [C x 77]   and   B_h = V_h W_o,h^T  [77 x C]
         // are computed once per sampling run (sd_unet_set_context; 80 key slots per head, 3 of them padding).
@@ -1177,10 +1166,34 @@ struct Builder {
         //  * SD_XATTN_FOLD (levels with <= n tokens, default 1024): two GEMMs with per-sample weights,
         //    P = softmax_77(X A) in the GEMM epilogue and h2 = h1 + P B + b_o;
         //  * otherwise to_q GEMM, the 77-key flash-attention kernel and the to_out GEMM.
+        // norm2 (round 5): folded into the first kernel of whichever form runs -- rstd from the row partials attn1.to_out's
+        // epilogue delivers, gamma in the operand (A^T centred over the channel: the row mean drops out; the plain to_q weights
+        // with the c1 correction), beta as a constant per key slot / output column.  SD_XATTN_LN=0: the separate LayerNorm launch.
         static const int fused_min_hw = getenv("SD_XATTN_FUSED") ? atoi(getenv("SD_XATTN_FUSED")) : 1024;
         static const int fold_max_hw = getenv("SD_XATTN_FOLD") ? atoi(getenv("SD_XATTN_FOLD")) : 1024;
+        static const bool xln_off = getenv("SD_XATTN_LN") && atoi(getenv("SD_XATTN_LN")) == 0;
         const int NH = u->cfg.num_heads, NP = NH * 80;
-        if (fused_min_hw > 0 && hw >= fused_min_hw && sd_xattn_fused_applicable(hw, C, NH, L)) {
+        const int xmode = (fused_min_hw > 0 && hw >= fused_min_hw && sd_xattn_fused_applicable(hw, C, NH, L)) ? 0
+                          : (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) ? 1 : 2;
+        int rs2 = -1, np2 = 0;
+        const long rs2_rows = (long)pl.ops[to_out_op].M;     // (< M when the CFG pair was replicated after attn1.to_out ran)
+        // (the set_context plan and the forward plan must agree on every operand it writes: the CFG-pair variant replicates the
+        // rows after attn1.to_out of the FIRST transformer only -- the fused kernel reads its partials modulo their rows, the
+        // GEMM consumers do not, so in the two GEMM forms that block keeps its LayerNorm in EVERY plan variant)
+        const bool first_tf = n_transformers++ == 0;
+        if (!fq && !xln_off && (xmode == 0 || (!first_tf && rs2_rows == M)) &&
+            u->woff.count(t + (xmode == 2 ? "attn2.to_q.weight.ln" : "attn2.to_q.weight.T.ln"))) {
+            if (first_tf) pl.ops[to_out_op].splitk = 1;      // (its row count differs between the plan variants: the split heuristic must not)
+            np2 = want_rowstats(pl.ops[to_out_op], (int)rs2_rows, C, rs2);
+        }
+        int n2 = np2 > 0 ? h1 : ln(h1, M, C, t + "norm2.weight", t + "norm2.bias");
+        // K|V of the prompt: projected once per sampling run by sd_unet_set_context
+        int kv = ctx_tensor((size_t)UB * L * 2 * C * 2);
+        pl.ctx_kv.push_back(kv);
+        pl.ctx_w.push_back(W(t + "attn2.kv.weight"));
+        pl.ctx_c.push_back(C);
+        int h2;
+        if (xmode == 0) {
             int at = ctx_tensor((size_t)UB * NP * C * 2), bw = ctx_tensor((size_t)UB * C * NP * 2);
             Plan::Fold fd{kv, at, bw, C, W(t + (np2 > 0 ? "attn2.to_q.weight.T.ln" : "attn2.to_q.weight.T")), W(t + "attn2.to_out.0.weight"), true};
             if (np2 > 0) { fd.c2 = ctx_tensor((size_t)UB * NP * 4); fd.lnu = W(t + "attn2.to_q.lnu"); }
@@ -1189,17 +1202,25 @@ struct Builder {
             o.sm_valid = L; o.b = W(t + "attn2.to_out.0.bias"); o.heads = NH;
             if (np2 > 0) { o.lnrs = rs2; o.lnnp = np2; o.s1 = fd.c2; o.ldx_o = rs2_rows; }   // (s1: the c2 tensor; ldx_o: rows of the partials)
             o.out = tensor((size_t)M * C * 2); push(o); h2 = o.out;
-        } else if (hw <= fold_max_hw && hw % 128 == 0 && L <= 80) {
+        } else if (xmode == 1) {
             int at = ctx_tensor((size_t)UB * NP * C * 2), bw = ctx_tensor((size_t)UB * C * NP * 2);
-            pl.ctx_fold.push_back({kv, at, bw, C, W(t + "attn2.to_q.weight.T"), W(t + "attn2.to_out.0.weight"), false});
+            Plan::Fold fd{kv, at, bw, C, W(t + (np2 > 0 ? "attn2.to_q.weight.T.ln" : "attn2.to_q.weight.T")), W(t + "attn2.to_out.0.weight"), false};
+            if (np2 > 0) {      // c1 = row sums of the ROUNDED centred operand (what is left of the mean term), c2 = the beta term
+                fd.c2 = ctx_tensor((size_t)UB * NP * 4); fd.lnu = W(t + "attn2.to_q.lnu");
+                fd.c1 = ctx_tensor((size_t)UB * NP * 4); fd.ones = W(t + "attn2.to_q.ones");
+            }
+            pl.ctx_fold.push_back(fd);
             int pr;
             { Op o; o.kind = OP_GEMM; o.x1 = n2; o.K1 = C; o.K = C; o.M = M; o.N = NP; o.epi = 2; o.sm_valid = L;
-              o.wt = at; o.wbs = (long)NP * C; o.rpb = hw; o.out = tensor((size_t)M * NP * 2); push(o); pr = o.out; }
+              o.wt = at; o.wbs = (long)NP * C; o.rpb = hw;
+              if (np2 > 0) { o.lnrs = rs2; o.lnnp = np2; o.s1 = fd.c1; o.s2 = fd.c2; }          // (s1 / s2: the per-sample c1 / c2 tensors)
+              o.out = tensor((size_t)M * NP * 2); push(o); pr = o.out; }
             { Op o; o.kind = OP_GEMM; o.x1 = pr; o.K1 = NP; o.K = NP; o.M = M; o.N = C; o.epi = 0;
               o.wt = bw; o.wbs = (long)C * NP; o.rpb = hw; o.b = W(t + "attn2.to_out.0.bias"); o.r = h1;
               o.out = tensor((size_t)M * C * 2); push(o); h2 = o.out; }
         } else {
-            int q2 = gemm(n2, C, -1, 0, M, C, t + "attn2.to_q.weight", "", -1, 0);
+            int q2 = np2 > 0 ? gemm_ln(h1, rs2, np2, M, C, C, t + "attn2.to_q.weight", 0)
+                             : gemm(n2, C, -1, 0, M, C, t + "attn2.to_q.weight", "", -1, 0);
             int a2 = attn(q2, 0, C, kv, 0, C, 2 * C, hw, L, C);
             h2 = gemm(a2, C, -1, 0, M, C, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", h1, 0);
         }
@@ -1634,6 +1655,7 @@ int run_op(sd_unet* u, const Plan& pl, const Op& o, char* ws, const float* laten
             a.rowstats = (float*)T(o.rs);
             if (o.hm) { a.hm_C = o.N / 3; a.hm_tok = o.HW; a.ldc = a.hm_C; a.KV = (bf16_t*)T(o.out) + (long)o.M * a.hm_C; }
             if (o.lnrs >= 0) { a.ln_rs = (const float*)T(o.lnrs); a.ln_np = o.lnnp; a.ln_c1 = (const float*)(wb + o.c1); a.ln_eps = 1e-5f; }
+            if (o.lnrs >= 0 && o.s1 >= 0) { a.ln_c1 = (const float*)T(o.s1); a.bias = (const float*)T(o.s2); a.ln_per_sample = 1; }   // per-sample weights
             return sd_launch_gemm(a, o.epi, stream);
         }
         case OP_LN:
@@ -1925,6 +1947,10 @@ extern "C" int sd_unet_set_context(sd_unet* u, void* stream, const float* ehs, i
             a.zero_page = g_zero_page;
             if ((rc = sd_launch_gemm(a, 0, (hipStream_t)stream))) return rc;
             if (f.perm && (rc = sd_launch_retile32(tmp, at_dst, unet_batch, NP, C, NP, (hipStream_t)stream))) return rc;
+        }
+        if (f.c1 >= 0) {    // what is left of the mean term: c1[sample][slot] = sum over the channel of the ROUNDED centred row
+            if ((rc = sd_launch_gemv((const float*)(u->dweights + f.ones), at_dst, nullptr, (float*)(ws + pl.tensors[f.c1].off),
+                                     unet_batch * NP, C, 0, (hipStream_t)stream))) return rc;
         }
         if (f.c2 >= 0) {    // beta term of every key slot: c2[sample][slot] = (scale K_h[slot]) . u   (fp32 GEMV over the expanded rows)
             if ((rc = sd_launch_gemv((const float*)(u->dweights + f.lnu), kexp, nullptr, (float*)(ws + pl.tensors[f.c2].off),
@@ -2263,6 +2289,22 @@ extern "C" int sd_op_gemm_batched(void* stream, const void* X, long long ldx, co
     a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
     a.w_batch_stride = w_batch_stride; a.rows_per_batch = rows_per_batch; a.sm_valid = sm_valid; a.splitk = 1;
     return sd_launch_gemm(a, epi, (hipStream_t)stream);
+}
+
+// the softmax-epilogue GEMM over per-sample weights with a LayerNorm folded in: X = the un-normalised rows, W = per-sample
+// [N][K] operands scaled by gamma (centred or not), c1 / c2 = per-sample [N] vectors (row sums of the rounded W, beta term),
+// rowstats [parts][M][2]: P = softmax_80col( rstd_m * (X W^T - mean_m c1) + c2 )
+extern "C" int sd_op_gemm_batched_softmax_ln(void* stream, const void* X, long long ldx, const void* W, long long w_batch_stride,
+                                             int rows_per_batch, void* C, long long ldc, int M, int N, int K, int sm_valid,
+                                             const float* rowstats, int parts, const float* c1, const float* c2, float eps) {
+    if (ensure_zero_page()) return -2;
+    SD_REQUIRE(rowstats && c1 && c2, "sd_op_gemm_batched_softmax_ln: null operand");
+    GemmArgs a;
+    a.X = (const bf16_t*)X; a.ldx = ldx; a.K1 = K; a.W = (const bf16_t*)W; a.bias = c2;
+    a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.zero_page = g_zero_page;
+    a.w_batch_stride = w_batch_stride; a.rows_per_batch = rows_per_batch; a.sm_valid = sm_valid; a.splitk = 1;
+    a.ln_rs = rowstats; a.ln_np = parts; a.ln_c1 = c1; a.ln_eps = eps; a.ln_per_sample = 1;
+    return sd_launch_gemm(a, 2, (hipStream_t)stream);
 }
 
 extern "C" int sd_op_conv3x3(void* stream, const void* X, const void* W, const float* bias, const float* bias2,

@@ -848,6 +848,41 @@ def test_gemm_batched_weights_and_grouped_softmax(sdlib, B, rows, N, K, epi):
         assert (o[..., 77:] == 0).all() and (o.sum(-1) - 1).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("B,rows,C,offset", [(3, 256, 1280, 0.8), (2, 128, 640, 0.0)])
+def test_gemm_per_sample_softmax_with_layernorm_folded(sdlib, B, rows, C, offset):
+    """First GEMM of the two-GEMM prompt cross-attention (16x16 level) with the block's norm2 folded in: P = softmax_77 over
+    every head's 80 key slots of LayerNorm(x) . A^T, computed from the UN-normalised rows, their (sum, sum of squares) partials,
+    the gamma-scaled per-sample operand and per-sample c1 / c2 vectors.  Against LayerNorm + einsum + softmax in fp64."""
+    g = torch.Generator().manual_seed(rows + C)
+    N, L, M = 640, 77, B * rows
+    x = r16(torch.randn(M, C, generator=g) * 0.8 + offset)
+    gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    w = (torch.randn(B, N, C, generator=g) / math.sqrt(C) * 3.0).double()
+    wg = w * gamma.double()
+    wln = r16((wg - wg.mean(-1, keepdim=True)).float())                  # centred, as the packer does for A^T
+    c1 = wln.double().sum(-1).float().contiguous()                          # [B, N]: what the centring leaves after rounding
+    c2 = (w @ beta.double()).float().contiguous()
+    parts = 2 * ((C + 159) // 160)
+    xs = x.double().view(M, C // 80, 80)
+    rs = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).permute(1, 0, 2).float().contiguous()
+    mean = x.double().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.double().var(-1, unbiased=False, keepdim=True) + 1e-5)
+    xn = ((x.double() - mean) * rstd * gamma.double() + beta.double()).view(B, rows, C)
+    S = torch.einsum("brk,bnk->brn", xn, w).view(B, rows, N // 80, 80)
+    ref = torch.zeros_like(S)
+    ref[..., :L] = torch.softmax(S[..., :L], dim=-1)
+    ref = ref.view(M, N).float()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    _lib.check(sdlib.sd_op_gemm_batched_softmax_ln(stream(), P(x, torch.bfloat16), C, P(wln, torch.bfloat16), N * C, rows, P(out), N,
+                                                   M, N, C, L, P(rs), parts, P(c1), P(c2), 1e-5))
+    torch.cuda.synchronize()
+    e = rel_l2(out, ref)
+    print(f"softmax GEMM + norm2 B={B} rows={rows} C={C} offset={offset}: {e:.3e}")
+    assert e < 1e-2                               # (bf16 rounding of the centred operand and of the probabilities)
+    o = out.float().view(M, N // 80, 80)
+    assert (o[..., L:] == 0).all() and (o.sum(-1) - 1).abs().max() < 2e-2
+
+
 @pytest.mark.parametrize("B,hw,C,spike", [(2, 256, 320, False), (1, 1024, 640, True), (3, 128, 1280, False), (2, 4096, 320, False),
                                           (2, 256, 320, 40.0), (1, 128, 1280, 40.0),
                                           (10, 4096, 320, False), (36, 1024, 640, True)])   # more token blocks than CUs: several rounds of workgroups
