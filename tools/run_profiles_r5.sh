@@ -25,7 +25,7 @@ traffic)   # HBM bytes of the dominant kernel AND of the HBM-bound ones (north_s
   for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/r5_pmc_traffic/$c
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/r5_pmc_traffic/$c -- python $R/tools/forward_once.py > $O/r5_pmc_traffic_$c.log 2>&1 || fail $O/r5_pmc_traffic_$c.log; done
   (cd $R && python tools/pmc_traffic_multi.py gpurun_out/r5_pmc_traffic gpurun_out/r5_conv_traffic.json "conv_halo_kernel<0, 0, 8, 0>" "conv_halo_kernel<0, 0, 8, 1>" \
-     "gn_apply_kernel" "gn_slab_kernel" "gn_finalize_stats_kernel" "layernorm_grouped_kernel" "gemm_lean_kernel<128, 160, 2, 2, 4, false>" "gemm_lean_kernel<256, 256, 4, 2, 2, true>" \
+     "gn_apply_kernel" "gn_slab_kernel" "gn_finalize_stats_kernel" "gemm_lean_kernel<128, 160, 2, 2, 4, false>" "gemm_lean_kernel<256, 256, 4, 2, 2, true>" \
      "gemm_lean_kernel<128, 160, 2, 2, 0, false>" "attn_pipe40_kernel" "xattn_fused_kernel" "splitk_reduce_kernel" | cut -c1-260) ;;
 xa)      # fused cross-attention: the 64-sample launch of rounds 2-4, the bench's own 16-sample launch, and LONG dispatches (512 / 2048
          # samples: 2.6 / 10 ms) -- GRBM_GUI_ACTIVE / 8 / time reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS
