@@ -356,7 +356,9 @@ def conv_stream_ceiling(ub, dev):
     return {"kernel_tflops": flops / tot[0] / 1e12, "bare_mfma_stream_tflops": flops / tot[8] / 1e12,
             "kernel_over_stream": tot[8] / tot[0],
             "what": "conv_halo_kernel at 64x64x320, 32x32x640, 16x16x1280 (UNet batch of this run), unmodified vs its bare MFMA "
-                    "stream (no LDS-DMA, barriers or fragment reads: sd_op_conv3x3_ablate 8 of libsdhip_ablate.so); measured in this run"}
+                    "stream (no LDS-DMA, barriers or fragment reads: sd_op_conv3x3_ablate 8 of libsdhip_ablate.so); measured in this run, at this "
+                    "batch: launch, fill and drain of 1-2 items per CU are in both numbers (a pure MFMA loop sustains 2.03 PFLOP/s and "
+                    "the ablated kernel 1.8-1.96 at many items per CU: profiles/round5_notes.md 9)"}
 
 
 def spawn_ranks(args) -> int:
